@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: BASELINE.json config C2 -- BatchDecodeWithPagedKVCacheWrapper, bf16, GQA 32/8,
+head_dim 128, page_size 16, batch 64, kv_len 8192 -- on N MI355X GPUs of one node.
+
+A "step" is one pass of the hot path (wrapper.run = decode kernel + split-KV merge kernel) over one batch
+of synthetic paged KV that is already resident in HBM.  Work is per-request data-parallel: every rank owns
+its own batch of 64 requests (weak scaling) and there is no data-path collective.
+
+    python bench.py                       # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` = algorithmic bytes (q + k + v + o, the reference's formula,
+flashinfer/testing/utils.py:476-480) of all ranks / the timed wall time (max over ranks).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "flashinfer-ai_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+C2 = dict(batch=64, kv_len=8192, num_qo_heads=32, num_kv_heads=8, head_dim=128, page_size=16)
+
+
+def algorithmic_bytes_flops(cfg, esize=2):
+    b, L, hq, hkv, d = cfg["batch"], cfg["kv_len"], cfg["num_qo_heads"], cfg["num_kv_heads"], cfg["head_dim"]
+    q = b * hq * d * esize
+    kv = 2 * b * L * hkv * d * esize
+    o = b * hq * d * esize
+    flops = 2 * b * 1 * L * hq * (d + d)  # ref: flashinfer/testing/utils.py:280-297 (non-causal)
+    return q + kv + o, flops
+
+
+def build_inputs(cfg, device, seed, permute=True):
+    b, L, hq, hkv, d, ps = (cfg[k] for k in ("batch", "kv_len", "num_qo_heads", "num_kv_heads", "head_dim", "page_size"))
+    g = torch.Generator(device=device).manual_seed(seed)
+    pages_per_req = L // ps
+    npages = b * pages_per_req
+    cache = torch.randn(npages, 2, ps, hkv, d, device=device, dtype=torch.bfloat16, generator=g)
+    q = torch.randn(b, hq, d, device=device, dtype=torch.bfloat16, generator=g)
+    indptr = (torch.arange(b + 1, dtype=torch.int32) * pages_per_req).to(device)
+    if permute:  # random page permutation is the headline case
+        indices = torch.randperm(npages, device=device, generator=g).to(torch.int32)
+    else:
+        indices = torch.arange(npages, device=device, dtype=torch.int32)
+    last = torch.full((b,), ps, dtype=torch.int32, device=device)
+    return q, cache, indptr, indices, last
+
+
+def cpu_baseline(cfg, sample_requests=8, iters=3):
+    """The reference's CPU path for this op ("torch-CPU SDPA"): pages gathered
+    into dense fp32 [B, Hkv, L, d], then F.scaled_dot_product_attention(enable_gqa=True) on the host cores.
+    Bounded sample: `sample_requests` requests of the same shape; gather time excluded."""
+    import torch.nn.functional as F
+
+    from oracle import attention_ref as R  # checker-side code, allowed here (cpu_baseline leg)
+
+    sub = dict(cfg, batch=sample_requests)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    q, cache, indptr, indices, last = build_inputs(sub, "cpu", seed=0)
+    ks, vs = [], []
+    for r in range(sample_requests):
+        k, v = R.gather_paged_kv(cache, "NHD", indptr, indices, last, r)
+        ks.append(k.float().transpose(0, 1))
+        vs.append(v.float().transpose(0, 1))
+    k = torch.stack(ks)  # [B, Hkv, L, d]
+    v = torch.stack(vs)
+    qq = q.float()[:, :, None, :]  # [B, Hq, 1, d]
+    times = []
+    for _ in range(iters):
+        t0 = time.perf_counter()
+        F.scaled_dot_product_attention(qq, k, v, enable_gqa=True)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    nbytes, _ = algorithmic_bytes_flops(sub)
+    return {
+        "value": nbytes / t / 1e9,
+        "unit": "GB/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{sample_requests} of 64 requests (kv_len 8192, 32/8 heads, d128), fp32 torch-CPU SDPA, "
+                  f"median of {iters}, gather excluded, {t * 1e3:.1f} ms",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-permute", action="store_true", help="arange page table instead of a random permutation")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if args.gpus != world and distributed:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    import flashinfer
+
+    cfg = C2
+    # every rank owns its own 64-request batch slice (disjoint pages, own page table): weak scaling
+    q, cache, indptr, indices, last = build_inputs(cfg, device, seed=rank, permute=not args.no_permute)
+    ws = torch.zeros(128 * 1024 * 1024, dtype=torch.uint8, device=device)
+    wrapper = flashinfer.BatchDecodeWithPagedKVCacheWrapper(ws, "NHD")
+    wrapper.plan(indptr, indices, last, cfg["num_qo_heads"], cfg["num_kv_heads"], cfg["head_dim"],
+                 cfg["page_size"], pos_encoding_mode="NONE", data_type=torch.bfloat16)
+    out = torch.empty_like(q)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wrapper.run(q, cache, out=out)
+    barrier()
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record()  # kernels are launched on torch's current stream, where these events live
+        wrapper.run(q, cache, out=out)
+        ends[i].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+
+    nbytes, flops = algorithmic_bytes_flops(cfg)
+    if rank == 0:
+        achieved = nbytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "c2_decode_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "paged_decode_hbm_bandwidth_bs64_kv8192_hd128",
+            "value": world * nbytes * args.steps / elapsed / 1e9,
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "C2: BatchDecodeWithPagedKVCacheWrapper bf16 GQA 32/8 head_dim=128 page_size=16 "
+                            "bs=64/GPU kv_len=8192, random page permutation" + (" (arange)" if args.no_permute else ""),
+                "batch_per_gpu": cfg["batch"], "kv_len": cfg["kv_len"], "num_qo_heads": cfg["num_qo_heads"],
+                "num_kv_heads": cfg["num_kv_heads"], "head_dim": cfg["head_dim"], "page_size": cfg["page_size"],
+                "split_kv": bool(wrapper._plan_info[9]), "kv_chunk_size": int(wrapper._plan_info[10]),
+                "parallelism": f"batch-shard x{world} (no data-path collective)",
+            },
+            "tflops": world * flops * args.steps / elapsed / 1e12,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "kernel": "fi::batch_decode_kernel (+ merge_n_kernel)",
+                "kernel_ms": kernel_ms,
+                "algorithmic_bytes_per_launch": nbytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+// Cascade merge kernels + their C-ABI entry points.
+#include "merge_kernel.h"
+
+namespace fi {
+
+// Merge n states per (row, head).  Ragged layout [nnz, H, D] (ref: VariableLengthMergeStates,
+// cascade.cuh:366-467) or dense [row, n, H, D] (ref: MergeStates, cascade.cuh:213-256).
+__global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNParams p) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * kMergeWaves + wave;
+  if (item >= (int64_t)p.seq_len * p.num_heads) return;
+  const int row = (int)(item / p.num_heads);
+  const int head = (int)(item % p.num_heads);
+  int64_t first;
+  int n;
+  if (p.indptr) {
+    first = p.indptr[row];
+    n = p.indptr[row + 1] - (int)first;
+  } else {
+    first = (int64_t)row * p.n_fixed;
+    n = p.n_fixed;
+  }
+  const int D = p.head_dim;
+  float acc[kMergeMaxPerLane];
+#pragma unroll
+  for (int k = 0; k < kMergeMaxPerLane; ++k) acc[k] = 0.f;
+  float m = -1.0e30f;
+  float dsum = 0.f;
+  for (int j = 0; j < n; ++j) {
+    const int64_t e = (first + j) * p.num_heads + head;
+    const float sj = p.s[e];
+    const float m_new = fmaxf(m, sj);
+    const float a = fast_exp2(m - m_new);
+    const float w = fast_exp2(sj - m_new);
+    dsum = dsum * a + w;
+    m = m_new;
+#pragma unroll
+    for (int k = 0; k < kMergeMaxPerLane; ++k) {
+      const int i = lane + 64 * k;
+      if (i < D) acc[k] = acc[k] * a + w * load_any_float(p.v, e * D + i, p.in_dtype);
+    }
+  }
+  const int64_t ob = ((int64_t)row * p.num_heads + head) * D;
+  // n == 0 -> zeros / -inf sentinel (ref: cascade.cuh:397-405)
+  const bool empty = !(dsum > 0.f);
+  const float inv = empty ? 0.f : 1.0f / dsum;
+#pragma unroll
+  for (int k = 0; k < kMergeMaxPerLane; ++k) {
+    const int i = lane + 64 * k;
+    if (i < D) store_any_float(p.v_out, ob + i, acc[k] * inv, p.out_dtype);
+  }
+  if (lane == 0 && p.s_out) p.s_out[(int64_t)row * p.num_heads + head] = empty ? FI_NEG_INF : m + fast_log2(dsum);
+}
+
+// ref: MergeStateKernel cascade.cuh:44-71 and MergeStateInPlaceKernel cascade.cuh:86-116
+// (in place: v_out == v_a, s_out == s_a).
+__global__ void __launch_bounds__(kMergeThreads) merge_2_kernel(const Merge2Params p) {
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * kMergeWaves + wave;
+  if (item >= (int64_t)p.seq_len * p.num_heads) return;
+  const int row = (int)(item / p.num_heads);
+  if (p.mask && !p.mask[row]) return;
+  const float sa = p.s_a[item], sb = p.s_b[item];
+  const float mx = fmaxf(sa, sb);
+  const float wa = fast_exp2(sa - mx), wb = fast_exp2(sb - mx);
+  const float inv = 1.0f / (wa + wb);
+  const float a_scale = wa * inv, b_scale = wb * inv;
+  const int D = p.head_dim;
+  const int64_t base = item * D;
+  for (int i = lane; i < D; i += 64) {
+    float va = load_any_float(p.v_a, base + i, p.dtype);
+    float vb = load_any_float(p.v_b, base + i, p.dtype);
+    store_any_float(p.v_out, base + i, a_scale * va + b_scale * vb, p.dtype);
+  }
+  if (lane == 0 && p.s_out) p.s_out[item] = fast_log2(wa + wb) + mx;
+}
+
+
+hipError_t launch_merge_n(const MergeNParams& p, hipStream_t stream) {
+  const int64_t items = (int64_t)p.seq_len * p.num_heads;
+  if (items == 0) return hipSuccess;
+  const int grid = (int)((items + kMergeWaves - 1) / kMergeWaves);
+  merge_n_kernel<<<dim3(grid), dim3(kMergeThreads), 0, stream>>>(p);
+  return hipGetLastError();
+}
+
+hipError_t launch_merge_2(const Merge2Params& p, hipStream_t stream) {
+  const int64_t items = (int64_t)p.seq_len * p.num_heads;
+  if (items == 0) return hipSuccess;
+  const int grid = (int)((items + kMergeWaves - 1) / kMergeWaves);
+  merge_2_kernel<<<dim3(grid), dim3(kMergeThreads), 0, stream>>>(p);
+  return hipGetLastError();
+}
+
+static bool merge_dtype_ok(int dt) {
+  return dt == FI_DTYPE_F16 || dt == FI_DTYPE_BF16 || dt == FI_DTYPE_F32;
+}
+
+}  // namespace fi
+
+using namespace fi;
+
+extern "C" FI_API int fi_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b,
+                              void* v_merged, float* s_merged, int32_t seq_len, int32_t num_heads,
+                              int32_t head_dim, int32_t dtype, fi_stream_t stream) {
+  FI_REQUIRE(v_a && s_a && v_b && s_b && v_merged, "merge_state: null tensor");
+  FI_REQUIRE(merge_dtype_ok(dtype), "merge_state: unsupported dtype %d", dtype);
+  FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "merge_state: head_dim %d unsupported", head_dim);
+  Merge2Params p{v_a, s_a, v_b, s_b, v_merged, s_merged, nullptr, seq_len, num_heads, head_dim, dtype};
+  FI_HIP_CALL(launch_merge_2(p, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" FI_API int fi_merge_state_in_place(void* v, float* s, const void* v_other, const float* s_other,
+                                       const uint8_t* mask, int32_t seq_len, int32_t num_heads,
+                                       int32_t head_dim, int32_t dtype, fi_stream_t stream) {
+  FI_REQUIRE(v && s && v_other && s_other, "merge_state_in_place: null tensor");
+  FI_REQUIRE(merge_dtype_ok(dtype), "merge_state_in_place: unsupported dtype %d", dtype);
+  FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "merge_state_in_place: head_dim %d unsupported", head_dim);
+  Merge2Params p{v, s, v_other, s_other, v, s, mask, seq_len, num_heads, head_dim, dtype};
+  FI_HIP_CALL(launch_merge_2(p, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" FI_API int fi_merge_states(const void* v, const float* s, void* v_merged, float* s_merged,
+                               int32_t num_index_sets, int32_t seq_len, int32_t num_heads,
+                               int32_t head_dim, int32_t dtype, fi_stream_t stream) {
+  FI_REQUIRE(v && s && v_merged, "merge_states: null tensor");
+  FI_REQUIRE(merge_dtype_ok(dtype), "merge_states: unsupported dtype %d", dtype);
+  FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "merge_states: head_dim %d unsupported", head_dim);
+  FI_REQUIRE(num_index_sets >= 0, "merge_states: negative num_index_sets");
+  MergeNParams p{v, s, nullptr, v_merged, s_merged, num_index_sets, seq_len, num_heads, head_dim, dtype, dtype};
+  FI_HIP_CALL(launch_merge_n(p, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" FI_API int fi_variable_length_merge_states(const void* v, const float* s, const int32_t* indptr,
+                                               void* v_merged, float* s_merged, int32_t seq_len,
+                                               int32_t num_heads, int32_t head_dim, int32_t in_dtype,
+                                               int32_t out_dtype, fi_stream_t stream) {
+  FI_REQUIRE(v && s && indptr && v_merged, "variable_length_merge_states: null tensor");
+  FI_REQUIRE(merge_dtype_ok(in_dtype) && merge_dtype_ok(out_dtype), "variable_length_merge_states: unsupported dtype");
+  FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "variable_length_merge_states: head_dim %d unsupported", head_dim);
+  MergeNParams p{v, s, indptr, v_merged, s_merged, 0, seq_len, num_heads, head_dim, in_dtype, out_dtype};
+  FI_HIP_CALL(launch_merge_n(p, (hipStream_t)stream));
+  return 0;
+}

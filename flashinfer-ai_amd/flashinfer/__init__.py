@@ -1,0 +1,21 @@
+"""flashinfer -- MI355X (gfx950) native implementation of FlashInfer's paged-KV attention hot path.
+
+Drop-in for the ``flashinfer.decode / prefill / cascade / page / gemm`` operator API of FlashInfer
+v0.3.1 (ref: flashinfer/__init__.py:23-145), backed by hand-written HIP kernels behind the C ABI of
+``libfi_mi355.so`` (include/fi_mi355.h).  Only the path named in DESIGN.md is provided.
+"""
+from . import _lib as _lib
+from .cascade import merge_state as merge_state
+from .cascade import merge_state_in_place as merge_state_in_place
+from .cascade import merge_states as merge_states
+from .decode import (
+    BatchDecodeWithPagedKVCacheWrapper as BatchDecodeWithPagedKVCacheWrapper,
+)
+from .decode import (
+    CUDAGraphBatchDecodeWithPagedKVCacheWrapper as CUDAGraphBatchDecodeWithPagedKVCacheWrapper,
+)
+from .decode import single_decode_with_kv_cache as single_decode_with_kv_cache
+from .page import get_seq_lens as get_seq_lens
+from .utils import next_positive_power_of_2 as next_positive_power_of_2
+
+__version__ = "0.3.1+mi355x.r1"

@@ -1,0 +1,201 @@
+/*
+ * fi_mi355.h -- C ABI of libfi_mi355.so, the MI355X (gfx950) implementation of FlashInfer's
+ * batch paged-KV attention hot path (decode / prefill / cascade merge / page append) and the fp8
+ * groupwise (grouped) GEMM.
+ *
+ * Every entry point replaces one TVM-FFI export of the reference (FlashInfer v0.3.1); the export it
+ * stands in for is cited as `ref: file:line` (paths relative to the reference checkout).  The
+ * reference passes DLPack tensor views; this ABI passes the same information as plain device pointers,
+ * element strides and sizes, so it can be bound from ctypes / cgo / JNI without torch types.
+ *
+ * Conventions
+ *   - return value: 0 on success, non-zero on failure; fi_last_error() returns a thread-local message
+ *     (the reference throws flashinfer::Error / TVM_FFI_ICHECK, ref: include/flashinfer/exception.h:23).
+ *   - all tensors are borrowed; outputs are pre-allocated by the caller
+ *     (ref: flashinfer/decode.py:1262-1275).
+ *   - `stream` is a hipStream_t passed as void* (the reference takes the current torch stream,
+ *     ref: csrc/tvm_ffi_utils.h:256-264).  No call synchronises the device.
+ *   - strides are in ELEMENTS, not bytes (as paged_kv_t, ref: include/flashinfer/page.cuh:127-145).
+ *   - log-sum-exp values are base 2 (ref: include/flashinfer/attention/state.cuh:45), and an empty
+ *     KV range yields o = 0, lse = FI_NEG_INF (-5e4, ref: include/flashinfer/math.cuh:32).
+ */
+#ifndef FI_MI355_H_
+#define FI_MI355_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FI_ABI_VERSION 1
+#define FI_NEG_INF (-5.0e4f)
+
+typedef void* fi_stream_t; /* hipStream_t */
+
+#if defined(FI_BUILDING_LIB)
+#define FI_API __attribute__((visibility("default")))
+#else
+#define FI_API
+#endif
+
+/* element types (ref: dtype dispatch in csrc/tvm_ffi_utils.h:70-200) */
+enum fi_dtype {
+  FI_DTYPE_F16 = 0,
+  FI_DTYPE_BF16 = 1,
+  FI_DTYPE_FP8_E4M3 = 2, /* OCP e4m3fn == torch.float8_e4m3fn */
+  FI_DTYPE_FP8_E5M2 = 3,
+  FI_DTYPE_F32 = 4
+};
+
+/* ref: flashinfer/utils.py:30-46 */
+enum fi_pos_encoding_mode { FI_POS_NONE = 0, FI_POS_ROPE_LLAMA = 1, FI_POS_ALIBI = 2 };
+enum fi_mask_mode { FI_MASK_NON_CAUSAL = 0, FI_MASK_CAUSAL = 1, FI_MASK_CUSTOM = 2 };
+
+/* ------------------------------------------------------------------------------------------------
+ * library / device information
+ * ---------------------------------------------------------------------------------------------- */
+FI_API const char* fi_last_error(void);
+FI_API int fi_abi_version(void);
+/* number of compute units the planner balances for (hipDeviceProp.multiProcessorCount of the current
+ * device, or FI_NUM_CUS from the environment, or 256 when no device is visible). */
+FI_API int fi_num_compute_units(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Paged KV cache view.  ref: paged_kv_t, include/flashinfer/page.cuh:37-210.
+ *   element offset of (page, head, entry, feat) = page*stride_page + head*stride_h + entry*stride_n + feat
+ *   kv_len(b) = (indptr[b+1]-indptr[b]-1)*page_size + last_page_len[b]   (0 when the request has no page)
+ * `indices == NULL` means the identity page table (page i of request 0 is physical page i): this is how
+ * a dense [kv_len, H, D] tensor is addressed by fi_single_decode_run.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fi_paged_kv {
+  const void* k_data;
+  const void* v_data;
+  const int32_t* indptr;        /* [batch_size+1] device */
+  const int32_t* indices;       /* [indptr[batch_size]] device */
+  const int32_t* last_page_len; /* [batch_size] device */
+  const int32_t* rope_pos_offset; /* optional [batch_size] device, NULL = 0 */
+  int64_t stride_page, stride_n, stride_h;
+  int32_t page_size;
+  int32_t num_kv_heads;
+  int32_t head_dim;
+  int32_t batch_size;
+  int32_t dtype; /* fi_dtype */
+} fi_paged_kv_t;
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch decode.  ref: BatchDecodeWithPagedKVCachePlan / Run, csrc/batch_decode.cu:39-79, 81-191;
+ * planner DecodePlan, include/flashinfer/attention/scheduler.cuh:424-493.
+ * ---------------------------------------------------------------------------------------------- */
+#define FI_DECODE_PLAN_INFO_LEN 16
+/* plan_info (int64[FI_DECODE_PLAN_INFO_LEN]); the reference's DecodePlanInfo has 10 entries
+ * (scheduler.cuh:391-402); entries 0..9 keep their meaning, 10.. are ours. */
+enum fi_decode_plan_slot {
+  FI_DP_PADDED_BATCH_SIZE = 0, /* number of (request, kv-chunk) work items launched */
+  FI_DP_V_OFFSET = 1,          /* byte offset of tmp_v in the float workspace */
+  FI_DP_S_OFFSET = 2,          /* byte offset of tmp_s in the float workspace */
+  FI_DP_REQUEST_INDICES_OFFSET = 3,
+  FI_DP_KV_TILE_INDICES_OFFSET = 4,
+  FI_DP_O_INDPTR_OFFSET = 5,
+  FI_DP_BLOCK_VALID_MASK_OFFSET = 6,
+  FI_DP_KV_CHUNK_SIZE_PTR_OFFSET = 7,
+  FI_DP_ENABLE_CUDA_GRAPH = 8,
+  FI_DP_SPLIT_KV = 9,
+  FI_DP_KV_CHUNK_SIZE = 10, /* tokens per chunk */
+  FI_DP_NUM_WORK = 11,      /* valid work items (<= padded) */
+  FI_DP_BATCH_SIZE = 12,
+  FI_DP_INT_BYTES_USED = 13,
+  FI_DP_MAGIC = 15
+};
+#define FI_DECODE_PLAN_MAGIC 0x4649444543ll /* "FIDEC" */
+
+/* Host-side planning.  Writes the work list into `pinned_int_ws` and, when `int_ws` is non-NULL,
+ * enqueues ONE host-to-device copy of it on `stream` (ref: scheduler.cuh:488-491).  `int_ws == NULL`
+ * plans on the host only (used by CPU tests).  `indptr_h` is the HOST copy of the page indptr.
+ * `max_grid_hint` <= 0 lets the library size the grid from the device (CUs x resident waves). */
+FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws,
+                         size_t int_ws_bytes, const int32_t* indptr_h, int32_t batch_size,
+                         int32_t num_qo_heads, int32_t num_kv_heads, int32_t page_size,
+                         int32_t enable_cuda_graph, int32_t head_dim, int32_t q_dtype,
+                         int32_t kv_dtype, int32_t max_grid_hint, int64_t* plan_info_out,
+                         fi_stream_t stream);
+
+typedef struct fi_batch_decode_params {
+  const void* q; /* [batch, num_qo_heads, head_dim], strides below */
+  int64_t q_stride_n, q_stride_h;
+  fi_paged_kv_t kv;
+  void* o;    /* [batch, num_qo_heads, head_dim] contiguous, dtype = q dtype */
+  float* lse; /* optional [batch, num_qo_heads] */
+  const float* alibi_slopes;    /* [num_qo_heads], used when pos_encoding_mode == FI_POS_ALIBI */
+  const int32_t* q_rope_offset; /* optional [batch]; NULL = kv_len-1 (ref: decode.cuh:445-450) */
+  int32_t num_qo_heads;
+  int32_t q_dtype;           /* FI_DTYPE_F16 / FI_DTYPE_BF16 */
+  int32_t pos_encoding_mode; /* fi_pos_encoding_mode */
+  int32_t window_left;       /* -1 = full */
+  float logits_soft_cap;     /* 0 = off */
+  float sm_scale;
+  float rope_rcp_scale; /* 1/rope_scale */
+  float rope_rcp_theta; /* 1/rope_theta */
+} fi_batch_decode_params_t;
+
+FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes, void* int_ws, size_t int_ws_bytes,
+                        const int64_t* plan_info, int32_t plan_info_len,
+                        const fi_batch_decode_params_t* params, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-request decode over a dense KV tensor.
+ * ref: single_decode_with_kv_cache, csrc/single_decode.cu:33-104; decode.cuh:658-737.
+ * k, v: [kv_len, num_kv_heads, head_dim] (NHD) or [num_kv_heads, kv_len, head_dim] (HND) described by
+ * strides.  `tmp` holds split-KV partial states (the reference uses a 32 MB cache buffer,
+ * flashinfer/decode.py:486).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fi_single_decode_params {
+  const void* q; /* [num_qo_heads, head_dim] */
+  int64_t q_stride_h;
+  const void* k;
+  const void* v;
+  int64_t kv_stride_n, kv_stride_h;
+  void* o;    /* [num_qo_heads, head_dim] */
+  float* lse; /* optional [num_qo_heads] */
+  const float* alibi_slopes;
+  int32_t kv_len, num_qo_heads, num_kv_heads, head_dim;
+  int32_t q_dtype, kv_dtype;
+  int32_t pos_encoding_mode;
+  int32_t window_left;
+  float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
+} fi_single_decode_params_t;
+
+FI_API int fi_single_decode_run(const fi_single_decode_params_t* params, void* tmp, size_t tmp_bytes,
+                         fi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention-state merge (cascade).  ref: csrc/cascade.cu:23-57 (merge_state), 59-100
+ * (merge_state_in_place), 102-... (merge_states); kernels include/flashinfer/attention/cascade.cuh.
+ *   (v, s) (+) (v', s'):  m = max(s, s'); w = 2^(s-m); w' = 2^(s'-m);
+ *   v_out = (w v + w' v') / (w + w');  s_out = m + log2(w + w')
+ * v: [seq_len, num_heads, head_dim] f16/bf16/f32 contiguous; s: [seq_len, num_heads] f32.
+ * ---------------------------------------------------------------------------------------------- */
+FI_API int fi_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b,
+                   void* v_merged, float* s_merged, int32_t seq_len, int32_t num_heads,
+                   int32_t head_dim, int32_t dtype, fi_stream_t stream);
+/* mask: optional uint8[seq_len]; rows with mask==0 keep (v, s) unchanged (cascade.cuh:86-116). */
+FI_API int fi_merge_state_in_place(void* v, float* s, const void* v_other, const float* s_other,
+                            const uint8_t* mask, int32_t seq_len, int32_t num_heads,
+                            int32_t head_dim, int32_t dtype, fi_stream_t stream);
+/* v: [seq_len, num_index_sets, num_heads, head_dim], s: [seq_len, num_index_sets, num_heads]. */
+FI_API int fi_merge_states(const void* v, const float* s, void* v_merged, float* s_merged,
+                    int32_t num_index_sets, int32_t seq_len, int32_t num_heads, int32_t head_dim,
+                    int32_t dtype, fi_stream_t stream);
+/* Ragged form used after split-KV (ref: VariableLengthMergeStates, cascade.cuh:686-736):
+ * v: [nnz, num_heads, head_dim] of in_dtype, s: [nnz, num_heads]; row r merges entries
+ * indptr[r]..indptr[r+1]; 0 entries -> zeros / FI_NEG_INF. */
+FI_API int fi_variable_length_merge_states(const void* v, const float* s, const int32_t* indptr,
+                                    void* v_merged, float* s_merged, int32_t seq_len,
+                                    int32_t num_heads, int32_t head_dim, int32_t in_dtype,
+                                    int32_t out_dtype, fi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FI_MI355_H_ */

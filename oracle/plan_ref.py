@@ -1,0 +1,67 @@
+"""Pure-Python restatement of the decode planner (integer work partitioning).
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Follows the reference's host scheduler:
+  PartitionPagedKVCacheBinarySearchMinNumPagePerBatch  include/flashinfer/attention/scheduler.cuh:73-99
+  BatchDecodeWithPagedKVCacheWorkEstimationDispatched  scheduler.cuh:183-207 (split decision)
+  DecodeSplitKVIndptr                                   scheduler.cuh:348-364
+  DecodePlan (padded batch, block_valid_mask)           scheduler.cuh:424-493
+The only build-specific inputs are `max_grid` (the reference derives it from CUDA occupancy x #SM; the
+MI355X planner uses CUs x resident waves) and `gdy` (work items per (request, chunk): the reference's
+gridDim.y = num_kv_heads; here num_kv_heads x q-head tiles).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+
+def ceil_div(a: int, b: int) -> int:
+    return (a + b - 1) // b
+
+
+def pick_head_tile(group_size: int) -> int:
+    if group_size <= 1:
+        return 1
+    if group_size == 2:
+        return 2
+    if group_size <= 4:
+        return 4
+    return 8
+
+
+def partition_pages(max_grid: int, gdy: int, num_pages: List[int], min_pages: int) -> Tuple[int, int]:
+    low, high = min_pages, max(num_pages + [0])
+    while low < high:
+        mid = (low + high) // 2
+        nb = sum(ceil_div(e, mid) for e in num_pages)
+        if nb * gdy > max_grid:
+            low = mid + 1
+        else:
+            high = mid
+    return low, sum(ceil_div(max(e, 1), low) for e in num_pages)
+
+
+def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, page_size: int,
+                    max_grid: int, enable_cuda_graph: bool = False):
+    batch = len(indptr) - 1
+    group = num_qo_heads // num_kv_heads
+    gdy = num_kv_heads * ceil_div(group, pick_head_tile(group))
+    num_pages = [indptr[i + 1] - indptr[i] for i in range(batch)]
+    if batch * gdy >= max_grid:
+        split, chunk_pages, new_batch = False, max(num_pages + [1]), batch
+    else:
+        chunk_pages, new_batch = partition_pages(max_grid, gdy, num_pages, max(128 // page_size, 1))
+        split = not (new_batch == batch and not enable_cuda_graph)
+    if enable_cuda_graph:
+        padded = max(max_grid // gdy, new_batch) if split else batch
+    else:
+        padded = new_batch
+    request_indices, kv_tile_indices, o_indptr = [], [], [0]
+    for b in range(batch):
+        n = ceil_div(max(num_pages[b], 1), chunk_pages) if split else 1
+        for t in range(n):
+            request_indices.append(b)
+            kv_tile_indices.append(t)
+        o_indptr.append(o_indptr[-1] + n)
+    return dict(split_kv=split, kv_chunk_size=chunk_pages * page_size, padded_batch_size=padded,
+                num_work=len(request_indices), request_indices=request_indices,
+                kv_tile_indices=kv_tile_indices, o_indptr=o_indptr)

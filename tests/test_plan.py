@@ -1,0 +1,100 @@
+"""CPU: the host planner behind the C ABI (host-only mode: int_ws = NULL) against the Python
+restatement of the reference scheduler (oracle/plan_ref.py)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+from oracle.plan_ref import decode_plan_ref
+
+
+def run_plan(fi_lib, indptr, hq, hkv, page_size, max_grid, cuda_graph=False, head_dim=128,
+             float_bytes=1 << 30):
+    from flashinfer import _lib
+
+    n = len(indptr) - 1
+    pinned = (C.c_char * (8 << 20))()
+    arr = (C.c_int32 * len(indptr))(*indptr)
+    info = (C.c_int64 * _lib.FI_DECODE_PLAN_INFO_LEN)()
+    rc = fi_lib.fi_batch_decode_plan(None, float_bytes, None, pinned, len(pinned), arr, n, hq, hkv,
+                                     page_size, int(cuda_graph), head_dim, 1, 1, max_grid, info, None)
+    assert rc == 0, fi_lib.fi_last_error()
+    info = list(info)
+    raw = np.frombuffer(pinned, dtype=np.uint8)
+
+    def i32(off, count):
+        return raw[off: off + 4 * count].view(np.int32).tolist()
+
+    padded, nwork = info[0], info[11]
+    out = dict(split_kv=bool(info[9]), kv_chunk_size=info[10], padded_batch_size=padded, num_work=nwork,
+               request_indices=i32(info[3], nwork), kv_tile_indices=i32(info[4], nwork),
+               o_indptr=i32(info[5], n + 1), chunk_ptr=i32(info[7], 1)[0], info=info)
+    if out["split_kv"]:
+        out["mask"] = raw[info[6]: info[6] + padded].tolist()
+    return out
+
+
+CASES = [
+    # (indptr, hq, hkv, page_size, max_grid)
+    ([0, 512], 32, 8, 16, 2048),
+    ([i * 512 for i in range(65)], 32, 8, 16, 2048),        # BASELINE config C2
+    ([i * 512 for i in range(65)], 32, 8, 16, 256),         # batch*heads >= grid: no split
+    ([0, 17, 29, 44, 48, 66, 100, 128], 64, 8, 16, 2048),   # ref doc example decode.py:602-610
+    ([0, 0, 9], 4, 4, 16, 64),                              # empty request (test_decode_prefill_lse.py)
+    ([0, 3, 3, 1000], 8, 1, 1, 512),
+    ([0, 5], 28, 4, 8, 4096),                               # group 7 -> head tile 8
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("cuda_graph", [False, True])
+def test_planner_matches_oracle(fi_lib, case, cuda_graph):
+    indptr, hq, hkv, ps, grid = case
+    got = run_plan(fi_lib, indptr, hq, hkv, ps, grid, cuda_graph)
+    exp = decode_plan_ref(indptr, hq, hkv, ps, grid, cuda_graph)
+    for key in ("split_kv", "kv_chunk_size", "padded_batch_size", "num_work", "request_indices",
+                "kv_tile_indices", "o_indptr"):
+        assert got[key] == exp[key], key
+    assert got["chunk_ptr"] == exp["kv_chunk_size"]
+    if got["split_kv"]:
+        assert got["mask"] == [1] * exp["num_work"] + [0] * (exp["padded_batch_size"] - exp["num_work"])
+
+
+def test_planner_random_page_tables(fi_lib):
+    rng = random.Random(0)
+    for _ in range(200):
+        b = rng.randint(1, 40)
+        ps = rng.choice([1, 4, 8, 16, 32])
+        pages = [rng.choice([0, 1, 2, rng.randint(1, 600)]) for _ in range(b)]
+        indptr = [0]
+        for p in pages:
+            indptr.append(indptr[-1] + p)
+        hkv = rng.choice([1, 2, 4, 8])
+        hq = hkv * rng.choice([1, 2, 3, 4, 5, 8, 16])
+        grid = rng.choice([64, 512, 2048, 4096])
+        cg = rng.random() < 0.3
+        got = run_plan(fi_lib, indptr, hq, hkv, ps, grid, cg)
+        exp = decode_plan_ref(indptr, hq, hkv, ps, grid, cg)
+        for key in ("split_kv", "kv_chunk_size", "padded_batch_size", "num_work", "request_indices",
+                    "kv_tile_indices", "o_indptr"):
+            assert got[key] == exp[key], (key, indptr, hq, hkv, ps, grid, cg)
+        # structural properties: chunks tile every request exactly
+        chunk_pages = got["kv_chunk_size"] // ps
+        for r in range(b):
+            n = got["o_indptr"][r + 1] - got["o_indptr"][r]
+            if got["split_kv"]:
+                assert n == max(1, -(-max(pages[r], 1) // chunk_pages))
+            else:
+                assert n == 1
+
+
+def test_workspace_too_small_is_an_error(fi_lib):
+    from flashinfer import _lib
+
+    indptr = (C.c_int32 * 2)(0, 4096)
+    pinned = (C.c_char * 4096)()
+    info = (C.c_int64 * _lib.FI_DECODE_PLAN_INFO_LEN)()
+    rc = fi_lib.fi_batch_decode_plan(None, 1024, None, pinned, 4096, indptr, 1, 32, 8, 16, 0, 128, 1, 1,
+                                     2048, info, None)
+    assert rc != 0 and b"workspace too small" in fi_lib.fi_last_error()
