@@ -125,7 +125,7 @@ def main():
     ws = torch.zeros(128 * 1024 * 1024, dtype=torch.uint8, device=device)
     wrapper = flashinfer.BatchDecodeWithPagedKVCacheWrapper(ws, "NHD")
     wrapper.plan(indptr, indices, last, cfg["num_qo_heads"], cfg["num_kv_heads"], cfg["head_dim"],
-                 cfg["page_size"], pos_encoding_mode="NONE", data_type=torch.bfloat16)
+                 cfg["page_size"], pos_encoding_mode="NONE", q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16)
     out = torch.empty_like(q)
 
     def barrier():

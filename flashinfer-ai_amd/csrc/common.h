@@ -157,7 +157,8 @@ struct KVTraits<FI_DTYPE_F16> {
     using h2 = __attribute__((ext_vector_type(2))) _Float16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      h2 h = __builtin_bit_cast(h2, r[i]);
+      const uint32_t w = r[i];  // copy first: bit_cast of a vector-element lvalue reads element 0
+      h2 h = __builtin_bit_cast(h2, w);
       f[2 * i] = (float)h[0];
       f[2 * i + 1] = (float)h[1];
     }

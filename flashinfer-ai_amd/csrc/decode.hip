@@ -228,8 +228,6 @@ static int fill_common(DecodeKernelParams& kp, int kv_dt, int head_dim, int num_
   kp.page_size = page_size;
   kp.log2_page_size = ilog2_exact(page_size);
   kp.uniform_page = kp.log2_page_size >= 0 && page_size >= tokens_per_load(kv_dt, head_dim);
-  if (const char* e = getenv("FI_DECODE_FORCE_GENERIC_PAGE"))
-    if (atoi(e)) kp.uniform_page = 0;
   kp.page_div = FastDiv((uint32_t)page_size);
   return gt;
 }
@@ -263,6 +261,8 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   FI_REQUIRE(a->pos_encoding_mode != FI_POS_ALIBI || a->alibi_slopes,
              "batch_decode_run: ALIBI needs alibi_slopes");
   const size_t esz = dtype_size(kv.dtype);
+  FI_REQUIRE(((uintptr_t)a->q % 16) == 0 && (a->q_stride_n * 2) % 16 == 0 && (a->q_stride_h * 2) % 16 == 0,
+             "batch_decode_run: q rows must be 16-byte aligned");
   FI_REQUIRE((kv.stride_n * esz) % 16 == 0 && (kv.stride_h * esz) % 16 == 0 &&
                  (kv.stride_page * esz) % 16 == 0 && ((uintptr_t)kv.k_data % 16) == 0 &&
                  ((uintptr_t)kv.v_data % 16) == 0,
@@ -318,6 +318,9 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
     kp.tmp_o = (float*)((char*)float_ws + plan_info[FI_DP_V_OFFSET]);
     kp.tmp_lse = (float*)((char*)float_ws + plan_info[FI_DP_S_OFFSET]);
   }
+  // fast path: scalar page ids, no logits transform, no window (see decode_kernel.h)
+  kp.fast_path = kp.uniform_page && kp.indices && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
+                 kp.window_left < 0 && !getenv("FI_DECODE_FORCE_GENERIC");
   if (kp.num_items > 0) {
     const int grid = ceil_div(kp.num_items, kDecodeWaves);
     FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
@@ -346,6 +349,8 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   FI_REQUIRE(a->pos_encoding_mode != FI_POS_ALIBI || a->alibi_slopes,
              "single_decode_run: ALIBI needs alibi_slopes");
   const size_t esz = dtype_size(a->kv_dtype);
+  FI_REQUIRE(((uintptr_t)a->q % 16) == 0 && (a->q_stride_h * 2) % 16 == 0,
+             "single_decode_run: q rows must be 16-byte aligned");
   FI_REQUIRE((a->kv_stride_n * esz) % 16 == 0 && (a->kv_stride_h * esz) % 16 == 0 &&
                  ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0,
              "single_decode_run: k/v rows must be 16-byte aligned");

@@ -17,8 +17,12 @@ constexpr int kNLoad = 4;
 
 template <int GT, bool ROPE>
 static hipError_t launch(const DecodeKernelParams& p, int grid, hipStream_t stream) {
-  batch_decode_kernel<FI_INST_KV_DT, FI_INST_HEAD_DIM, GT, ROPE, kNLoad>
-      <<<dim3(grid), dim3(kDecodeThreads), 0, stream>>>(p);
+  if (p.fast_path)
+    batch_decode_kernel<FI_INST_KV_DT, FI_INST_HEAD_DIM, GT, ROPE, true, kNLoad>
+        <<<dim3(grid), dim3(kDecodeThreads), 0, stream>>>(p);
+  else
+    batch_decode_kernel<FI_INST_KV_DT, FI_INST_HEAD_DIM, GT, ROPE, false, kNLoad>
+        <<<dim3(grid), dim3(kDecodeThreads), 0, stream>>>(p);
   return hipGetLastError();
 }
 

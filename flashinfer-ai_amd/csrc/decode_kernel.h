@@ -47,6 +47,7 @@ struct DecodeKernelParams {
   int32_t num_qo_heads, num_kv_heads, group_size, head_tiles;
   int32_t page_size, log2_page_size;
   int32_t uniform_page;  // page_size is a power of two >= tokens per load: one page id per load
+  int32_t fast_path;     // launch the FAST instantiation
   FastDiv page_div;
   int32_t kv_chunk_size;  // tokens; only read when split_kv
   int32_t split_kv;
@@ -62,8 +63,17 @@ struct DecodeKernelParams {
 __device__ __forceinline__ u32x4 load16(const void* base, int64_t byte_off) {
   return __builtin_nontemporal_load((const u32x4*)((const char*)base + byte_off));
 }
+// uniform base + 32-bit per-lane byte offset (global_load ... saddr form)
+__device__ __forceinline__ u32x4 load16(const char* ubase, uint32_t lane_byte_off) {
+  return __builtin_nontemporal_load((const u32x4*)(ubase + lane_byte_off));
+}
 
-template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, int NLOAD>
+// accurate sin/cos kept out of line: it is only used to (re)seed the rotation recurrences
+__device__ __attribute__((noinline)) static void sincos_ool(float x, float* sn, float* cs) {
+  sincosf(x, sn, cs);
+}
+
+template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD>
 struct DecodeWave {
   using T = KVTraits<KV_DT>;
   static constexpr int VEC = T::VEC;
@@ -76,6 +86,7 @@ struct DecodeWave {
   int lane, c, r;
   int kv_head, page_begin, kv_len, chunk_start, chunk_end, win_start;
   int64_t head_off;      // kv_head*stride_h
+  uint32_t lane_voff;    // (r*stride_n + c*VEC) * BYTES: per-lane byte offset inside a load (FAST)
   int rope_pos0;         // position offset of kv token 0
   float q[GT][VEC];
   float o[GT][VEC];
@@ -95,44 +106,59 @@ struct DecodeWave {
   };
 
   // ---- page ids for one tile -------------------------------------------------------------
-  // uniform_page: one scalar id per load.  Otherwise one id per lane per load.
+  // FAST (page_size a power of two >= TPL, real page table, full tiles): one SCALAR page id per load,
+  // so the load address is {scalar page base} + {per-lane constant offset} and costs no vector ALU.
+  // Generic: one page id per lane per load, token index clamped to the chunk end.
+  template <bool SCALAR>
   __device__ __forceinline__ void fetch_pages(int tile_tok0, int (&pg)[NLOAD]) const {
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
-      int tok0 = tile_tok0 + j * TPL;
-      if (p.uniform_page) {
-        tok0 = min(tok0, chunk_end - 1);
-        int pi = tok0 >> p.log2_page_size;
-        pg[j] = p.indices ? p.indices[page_begin + pi] : pi;
+      const int tok0 = tile_tok0 + j * TPL;
+      if constexpr (SCALAR) {
+        const int pi = min(tok0, chunk_end - 1) >> p.log2_page_size;
+        pg[j] = p.indices[page_begin + pi];
       } else {
-        int tok = min(tok0 + r, chunk_end - 1);
-        int pi = (int)fast_div((uint32_t)tok, p.page_div);
+        const int tok = min(tok0 + r, chunk_end - 1);
+        const int pi = (int)fast_div((uint32_t)tok, p.page_div);
         pg[j] = p.indices ? p.indices[page_begin + pi] : pi;
       }
     }
   }
 
+  template <bool SCALAR>
   __device__ __forceinline__ void issue_loads(int tile_tok0, const int (&pg)[NLOAD], Buf& b) const {
 #pragma unroll
     for (int j = 0; j < NLOAD; ++j) {
-      int tok0 = tile_tok0 + j * TPL;
-      int64_t off;
-      if (p.uniform_page) {
-        // whole load lies in one page unless clamped at the chunk end
-        int tok = min(tok0 + r, chunk_end - 1);
-        int entry = tok & (p.page_size - 1);
-        int page = __builtin_amdgcn_readfirstlane(pg[j]);
-        off = (int64_t)page * p.kv_stride_page + head_off + (int64_t)entry * p.kv_stride_n +
-              (int64_t)(c * VEC);
+      const int tok0 = tile_tok0 + j * TPL;
+      if constexpr (SCALAR) {
+        const int page = __builtin_amdgcn_readfirstlane(pg[j]);
+        const int entry0 = tok0 & (p.page_size - 1);
+        const int64_t sbase =
+            ((int64_t)page * p.kv_stride_page + head_off + (int64_t)entry0 * p.kv_stride_n) * T::BYTES;
+        b.k[j] = load16((const char*)p.k + sbase, lane_voff);
+        b.v[j] = load16((const char*)p.v + sbase, lane_voff);
       } else {
-        int tok = min(tok0 + r, chunk_end - 1);
-        int pi = (int)fast_div((uint32_t)tok, p.page_div);
-        int entry = tok - pi * p.page_size;
-        off = (int64_t)pg[j] * p.kv_stride_page + head_off + (int64_t)entry * p.kv_stride_n +
-              (int64_t)(c * VEC);
+        const int tok = min(tok0 + r, chunk_end - 1);
+        const int pi = (int)fast_div((uint32_t)tok, p.page_div);
+        const int entry = tok - pi * p.page_size;
+        const int64_t off = (int64_t)pg[j] * p.kv_stride_page + head_off +
+                            (int64_t)entry * p.kv_stride_n + (int64_t)(c * VEC);
+        b.k[j] = load16(p.k, off * T::BYTES);
+        b.v[j] = load16(p.v, off * T::BYTES);
       }
-      b.k[j] = load16(p.k, off * T::BYTES);
-      b.v[j] = load16(p.v, off * T::BYTES);
+    }
+  }
+
+  // 16-bit query words -> f32 (select instead of branch so that loads stay in flight)
+  static __device__ __forceinline__ void unpack_q(const u32x4 (&raw)[VEC / 8], bool is_bf16,
+                                                  float (&out)[VEC]) {
+#pragma unroll
+    for (int v8 = 0; v8 < VEC / 8; ++v8) {
+      float a[8], b[8];
+      KVTraits<FI_DTYPE_BF16>::unpack(raw[v8], a);
+      KVTraits<FI_DTYPE_F16>::unpack(raw[v8], b);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[8 * v8 + i] = is_bf16 ? a[i] : b[i];
     }
   }
 
@@ -143,7 +169,7 @@ struct DecodeWave {
       for (int i = 0; i < VEC; ++i) {
         float e = (float)pos * freq[i];
         float sn, cs;
-        sincosf(e, &sn, &cs);
+        sincos_ool(e, &sn, &cs);
         rc[i] = cs;
         rs[i] = sn;
       }
@@ -193,8 +219,10 @@ struct DecodeWave {
           acc2 = __builtin_elementwise_fma(qq, kk, acc2);
         }
         float acc = group_sum<LPT>(acc2[0] + acc2[1]);
-        if (p.use_alibi) acc += slope_l2[g] * (float)tok;  // ref: variants.cuh:67-70 (qo_idx = 0)
-        if (p.logits_soft_cap > 0.f) acc = fast_tanh(acc) * s_scale;  // ref: variants.cuh:71-73
+        if constexpr (!FAST) {
+          if (p.use_alibi) acc += slope_l2[g] * (float)tok;  // ref: variants.cuh:67-70 (qo_idx = 0)
+          if (p.logits_soft_cap > 0.f) acc = fast_tanh(acc) * s_scale;  // ref: variants.cuh:71-73
+        }
         if constexpr (MASKED) {
           bool valid = (tok < chunk_end) && (tok >= win_start);
           acc = valid ? acc : -INFINITY;
@@ -277,6 +305,7 @@ struct DecodeWave {
     //   visible iff kv_idx + 1 + window_left >= kv_len
     win_start = p.window_left >= 0 ? max(0, kv_len - 1 - p.window_left) : 0;
     head_off = (int64_t)kv_head * p.kv_stride_h;
+    lane_voff = (uint32_t)(((int64_t)r * p.kv_stride_n + c * VEC) * T::BYTES);
     rope_pos0 = p.kv_rope_pos_offset ? p.kv_rope_pos_offset[req] : 0;
 
     // ---- q: load, (rope), pre-scale ----
@@ -293,29 +322,41 @@ struct DecodeWave {
                   __powf(p.rope_rcp_theta,
                          (float)(2 * ((c * VEC + i) % (HEAD_DIM / 2))) / (float)HEAD_DIM);
         float sn, cs;
-        sincosf((float)TPL * freq[i], &sn, &cs);
+        sincos_ool((float)TPL * freq[i], &sn, &cs);
         dc[i] = cs;
         ds[i] = sn;
       }
     }
+    // all q loads are issued before the first one is consumed
+    u32x4 qraw[GT][VEC / 8], qraw_p[ROPE ? GT : 1][VEC / 8];
+    const int cp = (c + LPT / 2) % LPT;
 #pragma unroll
     for (int g = 0; g < GT; ++g) {
-      const int hg = ht * GT + g;
-      const int head = kv_head * p.group_size + min(hg, p.group_size - 1);
+      const int head = kv_head * p.group_size + min(ht * GT + g, p.group_size - 1);
       const int64_t qb = (int64_t)req * p.q_stride_n + (int64_t)head * p.q_stride_h;
-      float qv[VEC];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) qv[i] = load_f16_or_bf16(p.q, qb + c * VEC + i, p.q_dtype);
+      for (int v8 = 0; v8 < VEC / 8; ++v8) {
+        qraw[g][v8] = *(const u32x4*)((const uint16_t*)p.q + qb + c * VEC + 8 * v8);
+        if constexpr (ROPE)
+          qraw_p[g][v8] = *(const u32x4*)((const uint16_t*)p.q + qb + cp * VEC + 8 * v8);
+      }
+    }
+    const bool q_is_bf16 = p.q_dtype == FI_DTYPE_BF16;
+#pragma unroll
+    for (int g = 0; g < GT; ++g) {
+      const int head = kv_head * p.group_size + min(ht * GT + g, p.group_size - 1);
+      float qv[VEC];
+      unpack_q(qraw[g], q_is_bf16, qv);
       if constexpr (ROPE) {
         const int q_pos = p.q_rope_offset ? p.q_rope_offset[req] : (kv_len - 1);
-        const int cp = (c + LPT / 2) % LPT;
+        float partner[VEC];
+        unpack_q(qraw_p[g], q_is_bf16, partner);
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          float partner = load_f16_or_bf16(p.q, qb + cp * VEC + i, p.q_dtype);
           float e = (float)q_pos * freq[i];
           float sn, cs;
-          sincosf(e, &sn, &cs);
-          qv[i] = qv[i] * cs + ((c < LPT / 2) ? -partner : partner) * sn;
+          sincos_ool(e, &sn, &cs);
+          qv[i] = qv[i] * cs + ((c < LPT / 2) ? -partner[i] : partner[i]) * sn;
         }
       }
 #pragma unroll
@@ -330,48 +371,54 @@ struct DecodeWave {
 
     // ---- stream the chunk ----
     int first = chunk_start;
-    if (p.window_left >= 0 && win_start > chunk_start)
-      first = chunk_start + (win_start - chunk_start) / TILE * TILE;
+    if constexpr (!FAST) {
+      if (p.window_left >= 0 && win_start > chunk_start)
+        first = chunk_start + (win_start - chunk_start) / TILE * TILE;
+    }
     const int n_tok = chunk_end - first;
     if (n_tok > 0) {
-      const bool all_masked_mode = p.window_left >= 0;
+      const bool all_masked_mode = !FAST && p.window_left >= 0;
       const int ntot = (n_tok + TILE - 1) / TILE;
       const int nfull = all_masked_mode ? 0 : n_tok / TILE;
+      if constexpr (ROPE) rope_seed(rope_pos0 + first + r);
       int pgA[NLOAD], pgB[NLOAD];
       Buf A, B;
-      fetch_pages(first, pgA);
-      fetch_pages(first + TILE, pgB);
-      issue_loads(first, pgA, A);
-      if constexpr (ROPE) rope_seed(rope_pos0 + first + r);
       int t = 0;
-      while (true) {
-        // A holds tile t
-        bool has_next = t + 1 < ntot;
-        if (has_next) {
-          issue_loads(first + (t + 1) * TILE, pgB, B);
-          fetch_pages(first + (t + 2) * TILE, pgA);
-        }
-        if constexpr (ROPE)
-          if ((t & 15) == 0 && t) rope_seed(rope_pos0 + first + t * TILE + r);
-        if (t < nfull)
+      if (nfull > 0) {
+        // Software pipeline over the full tiles: while tile t is consumed from one register buffer,
+        // tile t+1 streams into the other and the page ids of tile t+2 are fetched.  The steady-state
+        // loop has NO branch around a load, so the compiler's vmcnt bookkeeping stays exact (a
+        // conditional prefetch makes it wait for the newest loads: measured r1).
+        fetch_pages<FAST>(first, pgA);
+        fetch_pages<FAST>(first + TILE, pgB);
+        issue_loads<FAST>(first, pgA, A);
+        while (t + 2 < nfull) {
+          issue_loads<FAST>(first + (t + 1) * TILE, pgB, B);
+          fetch_pages<FAST>(first + (t + 2) * TILE, pgA);
+          if constexpr (ROPE)
+            if ((t & 15) == 0 && t) rope_seed(rope_pos0 + first + t * TILE + r);
           compute<false>(first + t * TILE, A);
-        else
-          compute<true>(first + t * TILE, A);
-        if (!has_next) break;
-        ++t;
-        has_next = t + 1 < ntot;
-        if (has_next) {
-          issue_loads(first + (t + 1) * TILE, pgA, A);
-          fetch_pages(first + (t + 2) * TILE, pgB);
+          issue_loads<FAST>(first + (t + 2) * TILE, pgA, A);
+          fetch_pages<FAST>(first + (t + 3) * TILE, pgB);
+          compute<false>(first + (t + 1) * TILE, B);
+          t += 2;
         }
-        if constexpr (ROPE)
-          if ((t & 15) == 0) rope_seed(rope_pos0 + first + t * TILE + r);
-        if (t < nfull)
-          compute<false>(first + t * TILE, B);
-        else
-          compute<true>(first + t * TILE, B);
-        if (!has_next) break;
-        ++t;
+        if (nfull - t == 2) {
+          issue_loads<FAST>(first + (t + 1) * TILE, pgB, B);
+          compute<false>(first + t * TILE, A);
+          compute<false>(first + (t + 1) * TILE, B);
+          t += 2;
+        } else {
+          compute<false>(first + t * TILE, A);
+          t += 1;
+        }
+      }
+      // masked tiles (the partial last tile; every tile when a sliding window is active)
+      for (; t < ntot; ++t) {
+        fetch_pages<false>(first + t * TILE, pgA);
+        issue_loads<false>(first + t * TILE, pgA, A);
+        if constexpr (ROPE) rope_seed(rope_pos0 + first + t * TILE + r);
+        compute<true>(first + t * TILE, A);
       }
     }
 
@@ -436,13 +483,13 @@ struct DecodeWave {
   }
 };
 
-template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, int NLOAD>
-__global__ void __launch_bounds__(kDecodeThreads)
+template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD>
+__global__ void __launch_bounds__(kDecodeThreads, 2)
     batch_decode_kernel(const DecodeKernelParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x * kDecodeWaves + wave;
   if (item >= p.num_items) return;
-  DecodeWave<KV_DT, HEAD_DIM, GT, ROPE, NLOAD> w(p);
+  DecodeWave<KV_DT, HEAD_DIM, GT, ROPE, FAST, NLOAD> w(p);
   w.run(item);
 }
 

@@ -105,6 +105,7 @@ using namespace fi;
 extern "C" FI_API int fi_merge_state(const void* v_a, const float* s_a, const void* v_b, const float* s_b,
                               void* v_merged, float* s_merged, int32_t seq_len, int32_t num_heads,
                               int32_t head_dim, int32_t dtype, fi_stream_t stream) {
+  if (seq_len == 0 || num_heads == 0) return 0;
   FI_REQUIRE(v_a && s_a && v_b && s_b && v_merged, "merge_state: null tensor");
   FI_REQUIRE(merge_dtype_ok(dtype), "merge_state: unsupported dtype %d", dtype);
   FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "merge_state: head_dim %d unsupported", head_dim);
@@ -116,6 +117,7 @@ extern "C" FI_API int fi_merge_state(const void* v_a, const float* s_a, const vo
 extern "C" FI_API int fi_merge_state_in_place(void* v, float* s, const void* v_other, const float* s_other,
                                        const uint8_t* mask, int32_t seq_len, int32_t num_heads,
                                        int32_t head_dim, int32_t dtype, fi_stream_t stream) {
+  if (seq_len == 0 || num_heads == 0) return 0;
   FI_REQUIRE(v && s && v_other && s_other, "merge_state_in_place: null tensor");
   FI_REQUIRE(merge_dtype_ok(dtype), "merge_state_in_place: unsupported dtype %d", dtype);
   FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "merge_state_in_place: head_dim %d unsupported", head_dim);
@@ -127,7 +129,8 @@ extern "C" FI_API int fi_merge_state_in_place(void* v, float* s, const void* v_o
 extern "C" FI_API int fi_merge_states(const void* v, const float* s, void* v_merged, float* s_merged,
                                int32_t num_index_sets, int32_t seq_len, int32_t num_heads,
                                int32_t head_dim, int32_t dtype, fi_stream_t stream) {
-  FI_REQUIRE(v && s && v_merged, "merge_states: null tensor");
+  if (seq_len == 0 || num_heads == 0) return 0;
+  FI_REQUIRE((v && s || num_index_sets == 0) && v_merged, "merge_states: null tensor");
   FI_REQUIRE(merge_dtype_ok(dtype), "merge_states: unsupported dtype %d", dtype);
   FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "merge_states: head_dim %d unsupported", head_dim);
   FI_REQUIRE(num_index_sets >= 0, "merge_states: negative num_index_sets");
@@ -140,7 +143,8 @@ extern "C" FI_API int fi_variable_length_merge_states(const void* v, const float
                                                void* v_merged, float* s_merged, int32_t seq_len,
                                                int32_t num_heads, int32_t head_dim, int32_t in_dtype,
                                                int32_t out_dtype, fi_stream_t stream) {
-  FI_REQUIRE(v && s && indptr && v_merged, "variable_length_merge_states: null tensor");
+  if (seq_len == 0 || num_heads == 0) return 0;
+  FI_REQUIRE(indptr && v_merged, "variable_length_merge_states: null tensor");
   FI_REQUIRE(merge_dtype_ok(in_dtype) && merge_dtype_ok(out_dtype), "variable_length_merge_states: unsupported dtype");
   FI_REQUIRE(head_dim > 0 && head_dim <= 64 * kMergeMaxPerLane, "variable_length_merge_states: head_dim %d unsupported", head_dim);
   MergeNParams p{v, s, indptr, v_merged, s_merged, 0, seq_len, num_heads, head_dim, in_dtype, out_dtype};
