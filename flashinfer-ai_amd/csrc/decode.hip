@@ -48,10 +48,16 @@ static decode_launch_fn find_launcher(int kv_dt, int head_dim) {
 
 // q-head tile: the wave keeps GT query heads of one kv head in registers.
 static int pick_head_tile(int group_size) {
-  if (group_size <= 1) return 1;
-  if (group_size == 2) return 2;
-  if (group_size <= 4) return 4;
-  return 8;
+  static const int max_tile = [] {
+    const char* e = getenv("FI_DECODE_MAX_HEAD_TILE");
+    int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : 4;
+  }();
+  // groups larger than 4 are processed as several 4-head tiles by neighbouring waves of one workgroup
+  // (they stream the same K/V rows, so HBM sees them once): measured 1.7-1.9x faster than an 8-head tile,
+  // which is VALU-bound and spills (profiles/r01 notes in DESIGN.md).
+  int t = group_size <= 1 ? 1 : group_size == 2 ? 2 : 4;
+  return t < max_tile ? t : max_tile;
 }
 
 static int tokens_per_load(int kv_dt, int head_dim) {

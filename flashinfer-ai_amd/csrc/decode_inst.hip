@@ -35,7 +35,6 @@ hipError_t FI_LAUNCHER(const DecodeKernelParams& p, int gt, int rope, int grid,
     FI_CASE(1)
     FI_CASE(2)
     FI_CASE(4)
-    FI_CASE(8)
     default:
       return hipErrorInvalidValue;
   }

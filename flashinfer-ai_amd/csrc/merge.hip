@@ -5,6 +5,9 @@ namespace fi {
 
 // Merge n states per (row, head).  Ragged layout [nnz, H, D] (ref: VariableLengthMergeStates,
 // cascade.cuh:366-467) or dense [row, n, H, D] (ref: MergeStates, cascade.cuh:213-256).
+// Two passes so that no load depends on a previous one: (1) the n log-sum-exp values are read 64 at a
+// time, one per lane, and reduced to the row maximum and the weights' sum; (2) the value rows are
+// streamed with the weight of entry j broadcast from lane j.
 __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
@@ -22,25 +25,37 @@ __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNPara
     n = p.n_fixed;
   }
   const int D = p.head_dim;
+  // pass 1: maximum
+  float mx = -1.0e30f;
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    if (j < n) mx = fmaxf(mx, p.s[(first + j) * p.num_heads + head]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   float acc[kMergeMaxPerLane];
 #pragma unroll
   for (int k = 0; k < kMergeMaxPerLane; ++k) acc[k] = 0.f;
-  float m = -1.0e30f;
   float dsum = 0.f;
-  for (int j = 0; j < n; ++j) {
-    const int64_t e = (first + j) * p.num_heads + head;
-    const float sj = p.s[e];
-    const float m_new = fmaxf(m, sj);
-    const float a = fast_exp2(m - m_new);
-    const float w = fast_exp2(sj - m_new);
-    dsum = dsum * a + w;
-    m = m_new;
+  // pass 2
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    const float w_lane = j < n ? fast_exp2(p.s[(first + j) * p.num_heads + head] - mx) : 0.f;
+    dsum += w_lane;
+    const int cnt = min(64, n - j0);
+#pragma unroll 4
+    for (int jj = 0; jj < cnt; ++jj) {
+      const float w = __shfl(w_lane, jj, 64);
+      const int64_t e = (first + j0 + jj) * p.num_heads + head;
 #pragma unroll
-    for (int k = 0; k < kMergeMaxPerLane; ++k) {
-      const int i = lane + 64 * k;
-      if (i < D) acc[k] = acc[k] * a + w * load_any_float(p.v, e * D + i, p.in_dtype);
+      for (int k = 0; k < kMergeMaxPerLane; ++k) {
+        const int i = lane + 64 * k;
+        if (i < D) acc[k] += w * load_any_float(p.v, e * D + i, p.in_dtype);
+      }
     }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
   const int64_t ob = ((int64_t)row * p.num_heads + head) * D;
   // n == 0 -> zeros / -inf sentinel (ref: cascade.cuh:397-405)
   const bool empty = !(dsum > 0.f);
@@ -50,7 +65,8 @@ __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNPara
     const int i = lane + 64 * k;
     if (i < D) store_any_float(p.v_out, ob + i, acc[k] * inv, p.out_dtype);
   }
-  if (lane == 0 && p.s_out) p.s_out[(int64_t)row * p.num_heads + head] = empty ? FI_NEG_INF : m + fast_log2(dsum);
+  if (lane == 0 && p.s_out)
+    p.s_out[(int64_t)row * p.num_heads + head] = empty ? FI_NEG_INF : mx + fast_log2(dsum);
 }
 
 // ref: MergeStateKernel cascade.cuh:44-71 and MergeStateInPlaceKernel cascade.cuh:86-116

@@ -23,9 +23,7 @@ def pick_head_tile(group_size: int) -> int:
         return 1
     if group_size == 2:
         return 2
-    if group_size <= 4:
-        return 4
-    return 8
+    return 4
 
 
 def partition_pages(max_grid: int, gdy: int, num_pages: List[int], min_pages: int) -> Tuple[int, int]:
