@@ -88,6 +88,13 @@ __device__ __forceinline__ uint32_t fast_div(uint32_t n, const FastDiv& fd) {
   return (__umulhi(n, fd.m) + n) >> fd.l;
 }
 
+constexpr float kLog2e = 1.44269504088896340736f;
+
+// accurate sin/cos kept out of line: only used to seed rotations / in the fused-RoPE variants
+__device__ __attribute__((noinline)) static void sincos_ool(float x, float* sn, float* cs) {
+  sincosf(x, sn, cs);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

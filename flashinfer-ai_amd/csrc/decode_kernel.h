@@ -20,7 +20,6 @@ namespace fi {
 
 constexpr int kDecodeThreads = 256;  // 4 waves; waves are independent
 constexpr int kDecodeWaves = kDecodeThreads / 64;
-constexpr float kLog2e = 1.44269504088896340736f;
 constexpr float kMInit = -1.0e30f;  // finite "minus infinity" for the running max
 
 struct DecodeKernelParams {
@@ -66,11 +65,6 @@ __device__ __forceinline__ u32x4 load16(const void* base, int64_t byte_off) {
 // uniform base + 32-bit per-lane byte offset (global_load ... saddr form)
 __device__ __forceinline__ u32x4 load16(const char* ubase, uint32_t lane_byte_off) {
   return __builtin_nontemporal_load((const u32x4*)(ubase + lane_byte_off));
-}
-
-// accurate sin/cos kept out of line: it is only used to (re)seed the rotation recurrences
-__device__ __attribute__((noinline)) static void sincos_ool(float x, float* sn, float* cs) {
-  sincosf(x, sn, cs);
 }
 
 template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD>

@@ -1,0 +1,278 @@
+// Batch / single prefill: host planner, dispatcher and C-ABI entry points.
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "prefill_kernel.h"
+
+namespace fi {
+
+typedef hipError_t (*prefill_launch_fn)(const PrefillKernelParams&, int, hipStream_t);
+
+#define FI_PF_DECL(T, K, Q, D) \
+  hipError_t prefill_launch_##T##_##K##_##Q##_##D(const PrefillKernelParams&, int, hipStream_t);
+#define FI_PF_DECL_D(T, K, Q) FI_PF_DECL(T, K, Q, 64) FI_PF_DECL(T, K, Q, 128)
+// 16-bit q: kv of the same type, or fp8 kv upcast on the fly (ref: prefill.cuh:637-647, 993-1004)
+FI_PF_DECL_D(0, 0, 0) FI_PF_DECL_D(0, 2, 0) FI_PF_DECL_D(0, 3, 0)
+FI_PF_DECL_D(1, 1, 1) FI_PF_DECL_D(1, 2, 1) FI_PF_DECL_D(1, 3, 1)
+// fp8 q + fp8 kv (ref FA3 fp8 path), output type picks the compute type
+FI_PF_DECL_D(0, 2, 2) FI_PF_DECL_D(1, 2, 2)
+#undef FI_PF_DECL
+#undef FI_PF_DECL_D
+
+static prefill_launch_fn find_prefill(int t16, int kvs, int qs, int d) {
+#define FI_TRY(T, K, Q)                                       \
+  if (t16 == T && kvs == K && qs == Q) {                      \
+    if (d == 64) return prefill_launch_##T##_##K##_##Q##_64;  \
+    if (d == 128) return prefill_launch_##T##_##K##_##Q##_128; \
+    return nullptr;                                           \
+  }
+  FI_TRY(0, 0, 0) FI_TRY(0, 2, 0) FI_TRY(0, 3, 0)
+  FI_TRY(1, 1, 1) FI_TRY(1, 2, 1) FI_TRY(1, 3, 1)
+  FI_TRY(0, 2, 2) FI_TRY(1, 2, 2)
+#undef FI_TRY
+  return nullptr;
+}
+
+// compute type for (q dtype, o dtype)
+static int compute_type(int q_dt, int o_dt) {
+  if (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) return q_dt;
+  return o_dt;  // fp8 q: f16 or bf16 output decides
+}
+
+}  // namespace fi
+
+using namespace fi;
+
+extern "C" FI_API int fi_batch_prefill_plan(
+    void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws, size_t int_ws_bytes,
+    const int32_t* qo_indptr_h, const int32_t* kv_indptr_h, const int32_t* kv_len_arr_h,
+    int32_t total_num_rows, int32_t batch_size, int32_t num_qo_heads, int32_t num_kv_heads,
+    int32_t page_size, int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
+    int32_t causal, int32_t window_left, int32_t fixed_split_size, int32_t disable_split_kv,
+    int64_t* plan_info_out, fi_stream_t stream) {
+  (void)float_ws; (void)float_ws_bytes; (void)kv_indptr_h; (void)page_size; (void)window_left;
+  (void)fixed_split_size; (void)disable_split_kv;
+  FI_REQUIRE(pinned_int_ws && qo_indptr_h && kv_len_arr_h && plan_info_out,
+             "batch_prefill_plan: null argument");
+  FI_REQUIRE(batch_size >= 0, "batch_prefill_plan: negative batch size");
+  FI_REQUIRE(num_kv_heads > 0 && num_qo_heads % num_kv_heads == 0,
+             "batch_prefill_plan: num_qo_heads (%d) must be a multiple of num_kv_heads (%d)",
+             num_qo_heads, num_kv_heads);
+  FI_REQUIRE(head_dim_qk == head_dim_vo, "batch_prefill_plan: head_dim_qk != head_dim_vo unsupported");
+  FI_REQUIRE(head_dim_qk == 64 || head_dim_qk == 128,
+             "batch_prefill_plan: unsupported head_dim %d (64/128)", head_dim_qk);
+  FI_REQUIRE(qo_indptr_h[0] == 0, "batch_prefill_plan: qo_indptr[0] must be 0");
+  const int group = num_qo_heads / num_kv_heads;
+
+  // work list: one item per 128-row tile of GQA-packed queries (ref: PrefillSplitQOKVIndptr,
+  // scheduler.cuh:495-614 with packed_qo_len = qo_len * G).  Items are ordered longest-first
+  // (requests by kv_len descending, and for causal masks the later = heavier q tiles first) so the
+  // tail of the launch is made of the cheapest items (ref LPT idea: scheduler.cuh:900-946).
+  std::vector<int> order(batch_size);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int a, int b) { return kv_len_arr_h[a] > kv_len_arr_h[b]; });
+  std::vector<int32_t> req, tile;
+  for (int b : order) {
+    const int64_t qo_len = qo_indptr_h[b + 1] - qo_indptr_h[b];
+    FI_REQUIRE(qo_len >= 0, "batch_prefill_plan: qo_indptr must be non-decreasing");
+    const int64_t ntiles = ceil_div<int64_t>(qo_len * group, kTileQ);
+    for (int64_t t = 0; t < ntiles; ++t) {
+      req.push_back(b);
+      tile.push_back((int32_t)(causal ? ntiles - 1 - t : t));
+    }
+  }
+  size_t padded = req.size();
+  if (enable_cuda_graph) {
+    // fixed launch shape: the most tiles total_num_rows rows can ever form
+    const size_t bound = (size_t)ceil_div<int64_t>((int64_t)total_num_rows * group, kTileQ) + batch_size;
+    padded = std::max(padded, bound);
+  }
+  OffsetAllocator ia(int_ws_bytes);
+  const int64_t req_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
+  const int64_t tile_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
+  FI_REQUIRE(ia.ok, "batch_prefill_plan: int workspace too small (%zu bytes)", int_ws_bytes);
+  int32_t* req_h = (int32_t*)((char*)pinned_int_ws + req_off);
+  int32_t* tile_h = (int32_t*)((char*)pinned_int_ws + tile_off);
+  for (size_t i = 0; i < padded; ++i) {
+    req_h[i] = i < req.size() ? req[i] : -1;  // -1: padding item, the workgroup exits
+    tile_h[i] = i < tile.size() ? tile[i] : 0;
+  }
+  for (int i = 0; i < FI_PREFILL_PLAN_INFO_LEN; ++i) plan_info_out[i] = 0;
+  plan_info_out[FI_PP_PADDED_BATCH_SIZE] = (int64_t)padded;
+  plan_info_out[FI_PP_TOTAL_NUM_ROWS] = total_num_rows;
+  plan_info_out[FI_PP_CTA_TILE_Q] = kTileQ;
+  plan_info_out[FI_PP_REQUEST_INDICES_OFFSET] = req_off;
+  plan_info_out[FI_PP_QO_TILE_INDICES_OFFSET] = tile_off;
+  plan_info_out[FI_PP_ENABLE_CUDA_GRAPH] = enable_cuda_graph ? 1 : 0;
+  plan_info_out[FI_PP_SPLIT_KV] = 0;
+  plan_info_out[FI_PP_MAGIC] = FI_PREFILL_PLAN_MAGIC;
+  plan_info_out[6] = batch_size;
+  plan_info_out[7] = (int64_t)req.size();
+  if (int_ws && ia.used)
+    FI_HIP_CALL(hipMemcpyAsync(int_ws, pinned_int_ws, ia.used, hipMemcpyHostToDevice,
+                               (hipStream_t)stream));
+  return 0;
+}
+
+namespace fi {
+static int check_prefill_dtypes(const char* who, int q_dt, int kv_dt, int o_dt) {
+  FI_REQUIRE(o_dt == FI_DTYPE_F16 || o_dt == FI_DTYPE_BF16, "%s: output dtype must be f16/bf16", who);
+  if (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) {
+    FI_REQUIRE(o_dt == q_dt, "%s: output dtype must equal the 16-bit q dtype", who);
+    FI_REQUIRE(kv_dt == q_dt || kv_dt == FI_DTYPE_FP8_E4M3 || kv_dt == FI_DTYPE_FP8_E5M2,
+               "%s: kv dtype must equal q dtype or be fp8", who);
+  } else {
+    FI_REQUIRE(q_dt == FI_DTYPE_FP8_E4M3 && kv_dt == FI_DTYPE_FP8_E4M3,
+               "%s: fp8 attention needs e4m3 q, k and v", who);
+  }
+  return 0;
+}
+}  // namespace fi
+
+extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws_bytes, void* int_ws,
+                                                 size_t int_ws_bytes, const int64_t* plan_info,
+                                                 int32_t plan_info_len,
+                                                 const fi_batch_prefill_params_t* a,
+                                                 fi_stream_t stream_) {
+  (void)float_ws; (void)float_ws_bytes; (void)int_ws_bytes;
+  hipStream_t stream = (hipStream_t)stream_;
+  FI_REQUIRE(plan_info && plan_info_len == FI_PREFILL_PLAN_INFO_LEN &&
+                 plan_info[FI_PP_MAGIC] == FI_PREFILL_PLAN_MAGIC,
+             "batch_prefill_paged_run: plan_info is not a prefill plan (call plan() first)");
+  FI_REQUIRE(a && int_ws, "batch_prefill_paged_run: null argument");
+  const fi_paged_kv_t& kv = a->kv;
+  const int64_t num_work = plan_info[FI_PP_PADDED_BATCH_SIZE];
+  if (num_work == 0 || kv.batch_size == 0) return 0;
+  FI_REQUIRE(a->q && a->o && a->qo_indptr && kv.k_data && kv.v_data && kv.indptr && kv.last_page_len,
+             "batch_prefill_paged_run: null tensor");
+  FI_REQUIRE(kv.batch_size == plan_info[6], "batch_prefill_paged_run: batch size differs from the plan");
+  FI_REQUIRE(kv.num_kv_heads > 0 && a->num_qo_heads % kv.num_kv_heads == 0,
+             "batch_prefill_paged_run: num_qo_heads must be a multiple of num_kv_heads");
+  FI_REQUIRE(a->mask_mode == FI_MASK_NON_CAUSAL || a->mask_mode == FI_MASK_CAUSAL,
+             "batch_prefill_paged_run: custom masks are not supported yet");
+  if (check_prefill_dtypes("batch_prefill_paged_run", a->q_dtype, kv.dtype, a->o_dtype)) return 1;
+  const int t16 = compute_type(a->q_dtype, a->o_dtype);
+  prefill_launch_fn fn = find_prefill(t16, kv.dtype, a->q_dtype, kv.head_dim);
+  FI_REQUIRE(fn, "batch_prefill_paged_run: unsupported q/kv dtype %d/%d or head_dim %d", a->q_dtype,
+             kv.dtype, kv.head_dim);
+  FI_REQUIRE(a->pos_encoding_mode != FI_POS_ALIBI || a->alibi_slopes,
+             "batch_prefill_paged_run: ALIBI needs alibi_slopes");
+  const size_t qsz = dtype_size(a->q_dtype), ksz = dtype_size(kv.dtype);
+  FI_REQUIRE(((uintptr_t)a->q % 16) == 0 && (a->q_stride_n * qsz) % 8 == 0 &&
+                 (a->q_stride_h * qsz) % 8 == 0 && (qsz == 1 || ((a->q_stride_n * qsz) % 16 == 0 && (a->q_stride_h * qsz) % 16 == 0)),
+             "batch_prefill_paged_run: q rows must be 16-byte (8-byte for fp8) aligned");
+  FI_REQUIRE((kv.stride_n * ksz) % (8 * ksz) == 0 && (kv.stride_h * ksz) % (8 * ksz) == 0 &&
+                 (kv.stride_page * ksz) % (8 * ksz) == 0 && ((uintptr_t)kv.k_data % 16) == 0 &&
+                 ((uintptr_t)kv.v_data % 16) == 0,
+             "batch_prefill_paged_run: kv cache rows must be aligned to 8 elements");
+
+  PrefillKernelParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.q = a->q;
+  kp.o = a->o;
+  kp.lse = a->lse;
+  kp.k = kv.k_data;
+  kp.v = kv.v_data;
+  kp.qo_indptr = a->qo_indptr;
+  kp.kv_indptr = kv.indptr;
+  kp.kv_indices = kv.indices;
+  kp.kv_last_page_len = kv.last_page_len;
+  kp.request_indices = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_REQUEST_INDICES_OFFSET]);
+  kp.qo_tile_indices = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_QO_TILE_INDICES_OFFSET]);
+  kp.alibi_slopes = a->alibi_slopes;
+  kp.scale_q = a->scale_q;
+  kp.scale_k = a->scale_k;
+  kp.scale_v = a->scale_v;
+  kp.q_stride_n = a->q_stride_n;
+  kp.q_stride_h = a->q_stride_h;
+  kp.kv_stride_page = kv.stride_page;
+  kp.kv_stride_n = kv.stride_n;
+  kp.kv_stride_h = kv.stride_h;
+  kp.num_work = (int32_t)num_work;
+  kp.num_qo_heads = a->num_qo_heads;
+  kp.num_kv_heads = kv.num_kv_heads;
+  kp.group_size = a->num_qo_heads / kv.num_kv_heads;
+  kp.page_size = kv.page_size;
+  kp.page_div = FastDiv((uint32_t)kv.page_size);
+  kp.group_div = FastDiv((uint32_t)kp.group_size);
+  kp.causal = a->mask_mode == FI_MASK_CAUSAL;
+  kp.window_left = a->window_left;
+  kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
+  kp.o_dtype = a->o_dtype;
+  kp.fp8_p_quant = a->q_dtype == FI_DTYPE_FP8_E4M3;
+  kp.logits_soft_cap = a->logits_soft_cap > 0.f ? a->logits_soft_cap : 0.f;
+  kp.sm_scale = a->sm_scale;
+  kp.rope_rcp_scale = a->rope_rcp_scale;
+  kp.rope_rcp_theta = a->rope_rcp_theta;
+  FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
+  return 0;
+}
+
+extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a, void* tmp,
+                                            size_t tmp_bytes, fi_stream_t stream_) {
+  (void)tmp; (void)tmp_bytes;
+  hipStream_t stream = (hipStream_t)stream_;
+  FI_REQUIRE(a, "single_prefill_run: null params");
+  if (a->qo_len == 0) return 0;
+  FI_REQUIRE(a->q && a->k && a->v && a->o, "single_prefill_run: null tensor");
+  FI_REQUIRE(a->num_kv_heads > 0 && a->num_qo_heads % a->num_kv_heads == 0,
+             "single_prefill_run: num_qo_heads must be a multiple of num_kv_heads");
+  FI_REQUIRE(a->mask_mode == FI_MASK_NON_CAUSAL || a->mask_mode == FI_MASK_CAUSAL,
+             "single_prefill_run: custom masks are not supported yet");
+  if (check_prefill_dtypes("single_prefill_run", a->q_dtype, a->kv_dtype, a->o_dtype)) return 1;
+  const int t16 = compute_type(a->q_dtype, a->o_dtype);
+  prefill_launch_fn fn = find_prefill(t16, a->kv_dtype, a->q_dtype, a->head_dim);
+  FI_REQUIRE(fn, "single_prefill_run: unsupported q/kv dtype %d/%d or head_dim %d", a->q_dtype,
+             a->kv_dtype, a->head_dim);
+  FI_REQUIRE(a->pos_encoding_mode != FI_POS_ALIBI || a->alibi_slopes,
+             "single_prefill_run: ALIBI needs alibi_slopes");
+  const size_t qsz = dtype_size(a->q_dtype), ksz = dtype_size(a->kv_dtype);
+  FI_REQUIRE(((uintptr_t)a->q % 16) == 0 && (a->q_stride_n * qsz) % (8 * qsz) == 0 &&
+                 (a->q_stride_h * qsz) % (8 * qsz) == 0,
+             "single_prefill_run: q rows must be aligned to 8 elements");
+  FI_REQUIRE((a->kv_stride_n * ksz) % (8 * ksz) == 0 && (a->kv_stride_h * ksz) % (8 * ksz) == 0 &&
+                 ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0,
+             "single_prefill_run: k/v rows must be aligned to 8 elements");
+  const int vpage = 16;  // dense tensor == identity page table of 16-token pages
+  PrefillKernelParams kp;
+  memset(&kp, 0, sizeof(kp));
+  kp.q = a->q;
+  kp.o = a->o;
+  kp.lse = a->lse;
+  kp.k = a->k;
+  kp.v = a->v;
+  kp.alibi_slopes = a->alibi_slopes;
+  kp.scale_q = a->scale_q;
+  kp.scale_k = a->scale_k;
+  kp.scale_v = a->scale_v;
+  kp.q_stride_n = a->q_stride_n;
+  kp.q_stride_h = a->q_stride_h;
+  kp.kv_stride_page = (int64_t)vpage * a->kv_stride_n;
+  kp.kv_stride_n = a->kv_stride_n;
+  kp.kv_stride_h = a->kv_stride_h;
+  kp.num_qo_heads = a->num_qo_heads;
+  kp.num_kv_heads = a->num_kv_heads;
+  kp.group_size = a->num_qo_heads / a->num_kv_heads;
+  kp.num_work = (int32_t)ceil_div<int64_t>((int64_t)a->qo_len * kp.group_size, kTileQ);
+  kp.page_size = vpage;
+  kp.page_div = FastDiv((uint32_t)vpage);
+  kp.group_div = FastDiv((uint32_t)kp.group_size);
+  kp.single_qo_len = a->qo_len;
+  kp.single_kv_len = a->kv_len;
+  kp.causal = a->mask_mode == FI_MASK_CAUSAL;
+  kp.window_left = a->window_left;
+  kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
+  kp.o_dtype = a->o_dtype;
+  kp.fp8_p_quant = a->q_dtype == FI_DTYPE_FP8_E4M3;
+  kp.logits_soft_cap = a->logits_soft_cap > 0.f ? a->logits_soft_cap : 0.f;
+  kp.sm_scale = a->sm_scale;
+  kp.rope_rcp_scale = a->rope_rcp_scale;
+  kp.rope_rcp_theta = a->rope_rcp_theta;
+  FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
+  return 0;
+}

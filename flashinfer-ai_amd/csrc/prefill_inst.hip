@@ -1,0 +1,31 @@
+// One translation unit per (compute type, kv storage, q storage, head_dim); compiled by the Makefile with
+// -DFI_PF_T16=.. -DFI_PF_KVS=.. -DFI_PF_QS=.. -DFI_PF_D=..
+#include "prefill_kernel.h"
+
+#define FI_CAT5_(a, b, c, d, e) a##b##_##c##_##d##_##e
+#define FI_CAT5(a, b, c, d, e) FI_CAT5_(a, b, c, d, e)
+#define FI_LAUNCHER FI_CAT5(prefill_launch_, FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D)
+
+namespace fi {
+
+template <bool ROPE>
+static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
+  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE>;
+  constexpr int smem = 2 * 2 * kTileKV * FI_PF_D * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const int grid = p.num_work * p.num_kv_heads;
+  if (grid == 0) return hipSuccess;
+  kern<<<dim3(grid), dim3(kPrefillThreads), smem, stream>>>(p);
+  return hipGetLastError();
+}
+
+hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t stream) {
+  return rope ? launch<true>(p, stream) : launch<false>(p, stream);
+}
+
+}  // namespace fi

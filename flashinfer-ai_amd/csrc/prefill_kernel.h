@@ -1,0 +1,560 @@
+// Batch paged-KV prefill (flash) attention for gfx950: MFMA 32x32x16, wave64, LDS-staged K/V tiles.
+//
+// What it replaces: the reference's FA2 `BatchPrefillWithPagedKVCacheDevice`
+// (include/flashinfer/attention/prefill.cuh:2024-2413, mma.sync m16n8k16 tiles) and, for fp8 inputs,
+// the FA3 path (hopper/quantization/mainloop_mma.cuh:21-237; semantics hopper/variants.cuh:64-102).
+//
+// Structure (one workgroup = 4 waves = 128 GQA-packed query rows x one kv head):
+//   * GQA head-query fusion: packed row pr = qo_idx * G + head_in_group (ref: prefill.cuh:444-448), so
+//     the G query heads of a kv head share every K/V tile.
+//   * S^T = K . Q^T  ("swapped" product): A = K fragment read from LDS (ds_read_b128 of a swizzled
+//     [64 kv][D] image), B = Q fragment held in registers for the whole kernel.  The 32x32 accumulator
+//     then has the query row on the LANE and 16 kv positions in registers, so the online-softmax row
+//     reductions are in-lane plus one lane<->lane+32 exchange.
+//   * O^T += V^T . P^T: the S^T accumulator registers 8s..8s+7, rounded to 16 bit, ARE the B fragment of
+//     k-step s (no LDS round trip for P); V^T fragments come from the row-major V image in LDS through
+//     ds_read_b64_tr_b16 (hardware transpose), in the k order the accumulator layout dictates.
+//   * K/V tiles (64 kv rows) are gathered page by page with 16-byte loads into registers while the
+//     previous tile is being consumed, then written to the other LDS buffer (one barrier per tile); page
+//     ids are fetched two tiles ahead.
+//   * fp8 K/V/Q are upcast to the 16-bit compute type when staged (exact), so one MFMA pipeline serves
+//     fp16 / bf16 / fp8-KV / fp8-QKV; with fp8 Q the probabilities are rounded through e4m3 (x448) before
+//     P.V exactly as the reference does (hopper/variants.cuh:72, 84-90).
+#pragma once
+#include "common.h"
+
+namespace fi {
+
+constexpr int kPrefillThreads = 256;
+constexpr int kPrefillWaves = 4;
+constexpr int kTileQ = 128;   // packed query rows per workgroup
+constexpr int kTileKV = 64;   // kv rows per LDS tile
+
+struct PrefillKernelParams {
+  const void* q;
+  void* o;
+  float* lse;
+  const void* k;
+  const void* v;
+  const int32_t* qo_indptr;      // NULL: single request with single_qo_len rows
+  const int32_t* kv_indptr;      // NULL: single request, identity pages, single_kv_len
+  const int32_t* kv_indices;
+  const int32_t* kv_last_page_len;
+  const int32_t* request_indices;  // work list (NULL: request 0, tile = work index)
+  const int32_t* qo_tile_indices;
+  const float* alibi_slopes;
+  const float* scale_q;  // fp8: per qo head / kv head scales (NULL = 1)
+  const float* scale_k;
+  const float* scale_v;
+  int64_t q_stride_n, q_stride_h;
+  int64_t kv_stride_page, kv_stride_n, kv_stride_h;
+  int32_t num_work;
+  int32_t num_qo_heads, num_kv_heads, group_size;
+  int32_t page_size;
+  FastDiv page_div;
+  FastDiv group_div;
+  int32_t single_qo_len, single_kv_len;
+  int32_t causal;
+  int32_t window_left;  // < 0 off
+  int32_t use_alibi;
+  int32_t o_dtype;      // FI_DTYPE_F16 / BF16
+  int32_t fp8_p_quant;  // round P through e4m3 (fp8 Q path)
+  float logits_soft_cap;
+  float sm_scale;
+  float rope_rcp_scale, rope_rcp_theta;
+};
+
+template <int T16>
+struct MfmaType;
+template <>
+struct MfmaType<FI_DTYPE_F16> {
+  using elem = _Float16;
+  using frag = __attribute__((ext_vector_type(8))) _Float16;
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float x) { return f32_to_f16_bits(x); }
+  static __device__ __forceinline__ float to_f32(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+};
+template <>
+struct MfmaType<FI_DTYPE_BF16> {
+  using elem = __bf16;
+  using frag = __attribute__((ext_vector_type(8))) __bf16;
+  using f32x16 = __attribute__((ext_vector_type(16))) float;
+  static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float x) { return f32_to_bf16_bits(x); }
+  static __device__ __forceinline__ float to_f32(uint16_t b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+  }
+};
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+typedef __attribute__((address_space(3))) void lds_void;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+
+// 8 fp8 bytes -> 8 values of the 16-bit compute type, packed in a u32x4
+template <int T16, int FP8_DT>
+__device__ __forceinline__ u32x4 fp8x8_to_16(u32x2 raw) {
+  using M = MfmaType<T16>;
+  u32x4 out;
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    f32x2 lo, hi;
+    if constexpr (FP8_DT == FI_DTYPE_FP8_E4M3) {
+      lo = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[w], false);
+      hi = __builtin_amdgcn_cvt_pk_f32_fp8((int)raw[w], true);
+    } else {
+      lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw[w], false);
+      hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw[w], true);
+    }
+    out[2 * w] = (uint32_t)M::from_f32(lo[0]) | ((uint32_t)M::from_f32(lo[1]) << 16);
+    out[2 * w + 1] = (uint32_t)M::from_f32(hi[0]) | ((uint32_t)M::from_f32(hi[1]) << 16);
+  }
+  return out;
+}
+
+__device__ __forceinline__ float round_through_e4m3(float x) {
+  // x is already scaled into the e4m3 range; returns the e4m3-rounded value as f32
+  int packed = __builtin_amdgcn_cvt_pk_fp8_f32(x, 0.f, 0, false);
+  return __builtin_amdgcn_cvt_pk_f32_fp8(packed, false)[0];
+}
+
+// T16: MFMA compute type; KVS: K/V storage dtype; QS: Q storage dtype; D: head_dim (64 / 128)
+template <int T16, int KVS, int QS, int D, bool ROPE>
+__global__ void __launch_bounds__(kPrefillThreads, 2)
+    batch_prefill_kernel(const PrefillKernelParams p) {
+  using M = MfmaType<T16>;
+  using frag_t = typename M::frag;
+  constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
+  constexpr bool Q_FP8 = (QS == FI_DTYPE_FP8_E4M3 || QS == FI_DTYPE_FP8_E5M2);
+  constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
+  constexpr int ROWB = D * 2;             // bytes per row of the 16-bit LDS images
+  constexpr int CPR = D / 8;              // 16-byte chunks per row
+  constexpr int RPP = kPrefillThreads / CPR;  // rows staged per pass
+  constexpr int NPASS = kTileKV / RPP;
+  constexpr int KSTEPS = D / 16;          // MFMA k-steps over head_dim
+  constexpr int DBLK = D / 32;            // 32-row blocks of O^T
+  constexpr int TILE_BYTES = kTileKV * ROWB;
+  static_assert(D == 64 || D == 128, "head_dim 64 / 128");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [stage][K tile | V tile]
+  char* const lds_base = smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31;   // query column of this lane
+  const int lh = lane >> 5;   // lane half
+
+  // ---- which (request, q tile, kv head) ----
+  // Linear block id -> XCD-contiguous logical id (blocks b and b+8 share an XCD): every XCD gets a
+  // contiguous run of logical ids, and logical ids are ordered (kv head, work item) with the q tiles of
+  // one request adjacent, so workgroups that stream the same K/V pages share an L2.
+  const int total = p.num_work * p.num_kv_heads;
+  int logical;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  const int kv_head = logical / p.num_work;
+  const int work = logical - kv_head * p.num_work;
+  int req = 0, q_tile = work;
+  if (p.request_indices) {
+    req = p.request_indices[work];
+    q_tile = p.qo_tile_indices[work];
+    if (req < 0) return;  // padding item of a fixed-shape (graph) launch; uniform for the workgroup
+  }
+  int qo_start = 0, qo_len, kv_len, page_begin = 0;
+  if (p.qo_indptr) {
+    qo_start = p.qo_indptr[req];
+    qo_len = p.qo_indptr[req + 1] - qo_start;
+  } else {
+    qo_len = p.single_qo_len;
+  }
+  if (p.kv_indptr) {
+    page_begin = p.kv_indptr[req];
+    const int np = p.kv_indptr[req + 1] - page_begin;
+    kv_len = np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0;
+  } else {
+    kv_len = p.single_kv_len;
+  }
+  const int G = p.group_size;
+  const int packed_len = qo_len * G;
+  const int row0 = q_tile * kTileQ + wave * 32;  // first packed row of this wave
+  const int pr = row0 + lq;
+  const bool row_valid = pr < packed_len;
+  const int prc = row_valid ? pr : (packed_len > 0 ? packed_len - 1 : 0);
+  const int qo_idx = (int)fast_div((uint32_t)prc, p.group_div);
+  const int hg = prc - qo_idx * G;
+  const int qo_head = kv_head * G + hg;
+  // query position on the kv axis (ref: prefill.cuh:465-499, 782-786)
+  const int q_pos = kv_len - qo_len + qo_idx;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q, h) holds Q[q][16 ks + 8 h + 0..7] ----
+  frag_t qf[KSTEPS];
+  {
+    const int64_t qb = (int64_t)(qo_start + qo_idx) * p.q_stride_n + (int64_t)qo_head * p.q_stride_h;
+    u32x4 raw16[KSTEPS];
+    if constexpr (Q_FP8) {
+      u32x2 raw8[KSTEPS];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        raw8[ks] = *(const u32x2*)((const uint8_t*)p.q + qb + 16 * ks + 8 * lh);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) raw16[ks] = fp8x8_to_16<T16, QS>(raw8[ks]);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+        raw16[ks] = *(const u32x4*)((const uint16_t*)p.q + qb + 16 * ks + 8 * lh);
+    }
+    if constexpr (ROPE) {
+      // dims i and i + D/2 pair up: k-steps ks and ks + KSTEPS/2 of the same lane
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS / 2; ++ks) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          uint32_t lo_w = raw16[ks][w], hi_w = raw16[ks + KSTEPS / 2][w];
+          uint32_t out_lo = 0, out_hi = 0;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = 16 * ks + 8 * lh + 2 * w + e;  // < D/2
+            const float freq =
+                p.rope_rcp_scale * __powf(p.rope_rcp_theta, (float)(2 * i) / (float)D);
+            float sn, cs;
+            sincos_ool((float)q_pos * freq, &sn, &cs);
+            const float a = M::to_f32((uint16_t)(lo_w >> (16 * e)));
+            const float b = M::to_f32((uint16_t)(hi_w >> (16 * e)));
+            out_lo |= (uint32_t)M::from_f32(a * cs - b * sn) << (16 * e);
+            out_hi |= (uint32_t)M::from_f32(b * cs + a * sn) << (16 * e);
+          }
+          raw16[ks][w] = out_lo;
+          raw16[ks + KSTEPS / 2][w] = out_hi;
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) qf[ks] = __builtin_bit_cast(frag_t, raw16[ks]);
+  }
+
+  // ---- logits scale (ref: variants.cuh:47-53; fp8: hopper/variants.cuh:74-76) ----
+  const bool soft_cap = p.logits_soft_cap > 0.f;
+  float qk_scale = p.sm_scale;
+  if (p.scale_q) qk_scale *= p.scale_q[qo_head];
+  if (p.scale_k) qk_scale *= p.scale_k[kv_head];
+  const float c_log2 = qk_scale * kLog2e;
+  const bool plain_logits = !soft_cap && !p.use_alibi;
+  const float slope = p.use_alibi ? p.alibi_slopes[qo_head] : 0.f;
+
+  // ---- kv range of this workgroup ----
+  int kv_end = kv_len;
+  if (p.causal) {
+    // largest query position in the workgroup tile sees keys up to itself
+    const int last_pr = min(q_tile * kTileQ + kTileQ, packed_len) - 1;
+    const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
+    kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
+  }
+  const int num_tiles = (kv_end + kTileKV - 1) / kTileKV;
+  // smallest query position of this WAVE (wave-uniform): tiles ending at or below it need no causal mask
+  const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
+  const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
+
+  // ---- staging geometry ----
+  const int st_row = tid / CPR;  // row within a pass
+  const int st_ch = tid % CPR;   // 16-byte chunk (8 elements) within the row
+  const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
+
+  auto page_of = [&](int kvi) -> int {
+    const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+    return p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
+  };
+  auto fetch_pages = [&](int tile, int (&pg)[NPASS]) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int kvi = min(tile * kTileKV + ps * RPP + st_row, kv_len - 1);
+      pg[ps] = page_of(max(kvi, 0));
+    }
+  };
+  struct Stage {
+    u32x4 k[NPASS], v[NPASS];
+  };
+  auto issue_loads = [&](int tile, const int (&pg)[NPASS], Stage& st) {
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int kvi = max(min(tile * kTileKV + ps * RPP + st_row, kv_len - 1), 0);
+      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+      const int entry = kvi - pi * p.page_size;
+      const int64_t off = (int64_t)pg[ps] * p.kv_stride_page + head_off +
+                          (int64_t)entry * p.kv_stride_n + st_ch * 8;
+      if constexpr (KV_FP8) {
+        const u32x2 rk = *(const u32x2*)((const uint8_t*)p.k + off);
+        const u32x2 rv = *(const u32x2*)((const uint8_t*)p.v + off);
+        st.k[ps] = u32x4{rk[0], rk[1], 0, 0};
+        st.v[ps] = u32x4{rv[0], rv[1], 0, 0};
+      } else {
+        st.k[ps] = *(const u32x4*)((const uint16_t*)p.k + off);
+        st.v[ps] = *(const u32x4*)((const uint16_t*)p.v + off);
+      }
+    }
+  };
+  // swizzles (see header comment): K image for ds_read_b128, V image for ds_read_b64_tr_b16
+  auto k_lds_off = [&](int row, int ch) -> int {
+    const int sw = (CPR >= 16) ? (row & 15) : ((row >> 1) & 7);
+    return row * ROWB + ((ch ^ sw) << 4);
+  };
+  auto v_lds_off = [&](int row, int ch) -> int {
+    const int f = (ROWB >= 256) ? (row & 3) : ((row >> 1) & 1);
+    const int g64 = (ch >> 2) ^ f;
+    return row * ROWB + (g64 << 6) + ((ch & 3) << 4);
+  };
+  auto write_stage = [&](int tile, int buf, const Stage& st) {
+    char* kb = lds_base + buf * 2 * TILE_BYTES;
+    char* vb = kb + TILE_BYTES;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + st_row;
+      u32x4 kw, vw;
+      if constexpr (KV_FP8) {
+        kw = fp8x8_to_16<T16, KVS>(u32x2{st.k[ps][0], st.k[ps][1]});
+        vw = fp8x8_to_16<T16, KVS>(u32x2{st.v[ps][0], st.v[ps][1]});
+      } else {
+        kw = st.k[ps];
+        vw = st.v[ps];
+      }
+      if constexpr (ROPE) {
+        // rotate K at its absolute position; the partner chunk sits CPR/2 lanes away
+        const int kvi = tile * kTileKV + row;
+        u32x4 outw;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          uint32_t res = 0;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int i = st_ch * 8 + 2 * w + e;
+            const float freq = p.rope_rcp_scale *
+                               __powf(p.rope_rcp_theta, (float)(2 * (i % (D / 2))) / (float)D);
+            float sn, cs;
+            sincos_ool((float)kvi * freq, &sn, &cs);
+            const float x = M::to_f32((uint16_t)(kw[w] >> (16 * e)));
+            const float partner = __shfl_xor(x, CPR / 2, 64);
+            const float y = x * cs + ((st_ch < CPR / 2) ? -partner : partner) * sn;
+            res |= (uint32_t)M::from_f32(y) << (16 * e);
+          }
+          outw[w] = res;
+        }
+        kw = outw;
+      }
+      *(u32x4*)(kb + k_lds_off(row, st_ch)) = kw;
+      *(u32x4*)(vb + v_lds_off(row, st_ch)) = vw;
+    }
+  };
+
+  // ---- per-lane LDS read addresses ----
+  // K fragment (A operand): row 32 kb + lq, chunk (2 ks + lh) ^ swizzle(row)
+  int k_rd[KSTEPS];
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = k_lds_off(lq, 2 * ks + lh);
+  // V^T fragment via transposed read: within a 16-lane group, lane 4*q4 + p4 addresses row q4,
+  // columns 4 p4 .. 4 p4 + 3 of a 4 x 16 block; the group's block is rows 16 s + 4 lh + (0..3) [+8],
+  // columns 32 db + 16 gpar + (0..15)
+  const int q4 = (lane & 15) >> 2, p4 = lane & 3, gpar = (lane >> 4) & 1;
+  int v_rd[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db) {
+    const int row = 4 * lh + q4;
+    const int col_byte = (32 * db + 16 * gpar + 4 * p4) * 2;
+    const int f = (ROWB >= 256) ? (row & 3) : ((row >> 1) & 1);
+    v_rd[db] = row * ROWB + ((((col_byte >> 6) ^ f)) << 6) + (col_byte & 63);
+  }
+
+  // ---- running state ----
+  f32x16 o_acc[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  if (num_tiles > 0) {
+    int pgA[NPASS], pgB[NPASS];
+    Stage st;
+    fetch_pages(0, pgA);
+    issue_loads(0, pgA, st);
+    fetch_pages(1, pgB);
+    write_stage(0, 0, st);
+    __syncthreads();
+    for (int t = 0; t < num_tiles; ++t) {
+      const int buf = t & 1;
+      const bool has_next = t + 1 < num_tiles;
+      if (has_next) {
+        // even/odd page-id registers alternate
+        if (buf == 0) {
+          issue_loads(t + 1, pgB, st);
+          fetch_pages(t + 2, pgA);
+        } else {
+          issue_loads(t + 1, pgA, st);
+          fetch_pages(t + 2, pgB);
+        }
+      }
+      const char* kb = lds_base + buf * 2 * TILE_BYTES;
+      const char* vb = kb + TILE_BYTES;
+      const int tile0 = t * kTileKV;
+
+      // ---- S^T = K Q^T ----
+      f32x16 s_acc[2];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) {
+          const u32x4 a = *(const u32x4*)(kb + kbk * 32 * ROWB + k_rd[ks]);
+          s_acc[kbk] = M::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc[kbk]);
+        }
+      }
+
+      // ---- logits transform + mask (ref: variants.cuh:67-91, prefill.cuh:782-786) ----
+      const bool need_mask = (tile0 + kTileKV > kv_len) ||
+                             (p.causal && tile0 + kTileKV - 1 > min_qpos_wave) ||
+                             (p.window_left >= 0);
+      float x[2][16];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s = s_acc[kbk][r];
+          const int kv_idx = tile0 + 32 * kbk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (plain_logits) {
+            s *= c_log2;
+          } else {
+            // ref: variants.cuh:67-76 -- alibi bias, then soft cap, then the base-2 scale
+            float lg = s * qk_scale;
+            if (p.use_alibi) lg += slope * (float)(kv_idx - qo_idx);
+            if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg / p.logits_soft_cap);
+            s = lg * kLog2e;
+          }
+          x[kbk][r] = s;
+        }
+      }
+      if (need_mask) {
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv_idx = tile0 + 32 * kbk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            bool vis = kv_idx < kv_len;
+            if (p.causal) vis = vis && (kv_idx <= q_pos);
+            if (p.window_left >= 0) vis = vis && (kv_idx + p.window_left >= q_pos);
+            x[kbk][r] = vis ? x[kbk][r] : -INFINITY;
+          }
+        }
+      }
+
+      // ---- online softmax (base 2; ref: prefill.cuh:861-953) ----
+      float mx = x[0][0];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, x[kbk][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          x[kbk][r] = fast_exp2(x[kbk][r] - m_new);
+          psum += x[kbk][r];
+        }
+      l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+      }
+
+      // ---- P^T fragments: accumulator registers 8s..8s+7 of block kb are k-step s ----
+      frag_t pf[2][2];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          u32x4 w;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float a = x[kbk][8 * s + 2 * j], b = x[kbk][8 * s + 2 * j + 1];
+            if (p.fp8_p_quant) {  // ref: hopper/variants.cuh:84-90 -- P * 448 rounded to e4m3
+              a = round_through_e4m3(a * 448.f);
+              b = round_through_e4m3(b * 448.f);
+            }
+            w[j] = (uint32_t)M::from_f32(a) | ((uint32_t)M::from_f32(b) << 16);
+          }
+          pf[kbk][s] = __builtin_bit_cast(frag_t, w);
+        }
+
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            const char* base = vb + (32 * kbk + 16 * s) * ROWB + v_rd[db];
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(base + 8 * ROWB));
+            using s16x8 = __attribute__((ext_vector_type(8))) short;
+            const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pf[kbk][s], o_acc[db]);
+          }
+        }
+      }
+
+      if (has_next) write_stage(t + 1, buf ^ 1, st);
+      __syncthreads();
+    }
+  }
+
+  // ---- finalize (ref: prefill.cuh:2378-2403; fp8: attention_updater.cuh:221-240) ----
+  l_run += __shfl_xor(l_run, 32, 64);
+  const bool empty = !(l_run > 0.f);
+  float inv = empty ? 0.f : 1.0f / l_run;
+  if (p.fp8_p_quant) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
+  else if (p.scale_v) inv *= p.scale_v[kv_head];
+  if (row_valid) {
+    const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = 32 * db + 8 * r4 + 4 * lh;
+        uint32_t w0, w1;
+        {
+          const uint32_t a = f32_to_16bit(o_acc[db][4 * r4 + 0] * inv, p.o_dtype);
+          const uint32_t b = f32_to_16bit(o_acc[db][4 * r4 + 1] * inv, p.o_dtype);
+          const uint32_t c = f32_to_16bit(o_acc[db][4 * r4 + 2] * inv, p.o_dtype);
+          const uint32_t d = f32_to_16bit(o_acc[db][4 * r4 + 3] * inv, p.o_dtype);
+          w0 = a | (b << 16);
+          w1 = c | (d << 16);
+        }
+        *(u32x2*)((uint16_t*)p.o + ob + d0) = u32x2{w0, w1};
+      }
+    }
+    if (p.lse && lh == 0)
+      p.lse[(int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head] =
+          empty ? FI_NEG_INF : m_run + fast_log2(l_run);
+  }
+}
+
+}  // namespace fi

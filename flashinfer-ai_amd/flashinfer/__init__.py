@@ -16,6 +16,13 @@ from .decode import (
 )
 from .decode import single_decode_with_kv_cache as single_decode_with_kv_cache
 from .page import get_seq_lens as get_seq_lens
+from .prefill import (
+    BatchPrefillWithPagedKVCacheWrapper as BatchPrefillWithPagedKVCacheWrapper,
+)
+from .prefill import single_prefill_with_kv_cache as single_prefill_with_kv_cache
+from .prefill import (
+    single_prefill_with_kv_cache_return_lse as single_prefill_with_kv_cache_return_lse,
+)
 from .utils import next_positive_power_of_2 as next_positive_power_of_2
 
 __version__ = "0.3.1+mi355x.r1"

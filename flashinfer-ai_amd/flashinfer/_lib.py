@@ -101,6 +101,67 @@ class SingleDecodeParams(C.Structure):
     ]
 
 
+class BatchPrefillParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p),
+        ("q_stride_n", C.c_int64),
+        ("q_stride_h", C.c_int64),
+        ("qo_indptr", C.c_void_p),
+        ("kv", PagedKV),
+        ("o", C.c_void_p),
+        ("lse", C.c_void_p),
+        ("alibi_slopes", C.c_void_p),
+        ("scale_q", C.c_void_p),
+        ("scale_k", C.c_void_p),
+        ("scale_v", C.c_void_p),
+        ("num_qo_heads", C.c_int32),
+        ("q_dtype", C.c_int32),
+        ("o_dtype", C.c_int32),
+        ("mask_mode", C.c_int32),
+        ("pos_encoding_mode", C.c_int32),
+        ("window_left", C.c_int32),
+        ("logits_soft_cap", C.c_float),
+        ("sm_scale", C.c_float),
+        ("rope_rcp_scale", C.c_float),
+        ("rope_rcp_theta", C.c_float),
+    ]
+
+
+class SinglePrefillParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p),
+        ("q_stride_n", C.c_int64),
+        ("q_stride_h", C.c_int64),
+        ("k", C.c_void_p),
+        ("v", C.c_void_p),
+        ("kv_stride_n", C.c_int64),
+        ("kv_stride_h", C.c_int64),
+        ("o", C.c_void_p),
+        ("lse", C.c_void_p),
+        ("alibi_slopes", C.c_void_p),
+        ("scale_q", C.c_void_p),
+        ("scale_k", C.c_void_p),
+        ("scale_v", C.c_void_p),
+        ("qo_len", C.c_int32),
+        ("kv_len", C.c_int32),
+        ("num_qo_heads", C.c_int32),
+        ("num_kv_heads", C.c_int32),
+        ("head_dim", C.c_int32),
+        ("q_dtype", C.c_int32),
+        ("kv_dtype", C.c_int32),
+        ("o_dtype", C.c_int32),
+        ("mask_mode", C.c_int32),
+        ("pos_encoding_mode", C.c_int32),
+        ("window_left", C.c_int32),
+        ("logits_soft_cap", C.c_float),
+        ("sm_scale", C.c_float),
+        ("rope_rcp_scale", C.c_float),
+        ("rope_rcp_theta", C.c_float),
+    ]
+
+
+FI_PREFILL_PLAN_INFO_LEN = 16
+
 _lib: Optional[C.CDLL] = None
 
 # every symbol include/fi_mi355.h declares; tests check the library exports all of them
@@ -115,6 +176,9 @@ EXPORTED_SYMBOLS = [
     "fi_merge_state_in_place",
     "fi_merge_states",
     "fi_variable_length_merge_states",
+    "fi_batch_prefill_plan",
+    "fi_batch_prefill_paged_run",
+    "fi_single_prefill_run",
 ]
 
 
@@ -140,6 +204,9 @@ def lib() -> C.CDLL:
     l.fi_merge_state_in_place.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     l.fi_merge_states.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.fi_variable_length_merge_states.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    l.fi_batch_prefill_plan.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp] + [i32] * 12 + [i64p, vp]
+    l.fi_batch_prefill_paged_run.argtypes = [vp, sz, vp, sz, i64p, i32, C.POINTER(BatchPrefillParams), vp]
+    l.fi_single_prefill_run.argtypes = [C.POINTER(SinglePrefillParams), vp, sz, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(l, name)
         if name not in ("fi_last_error",):

@@ -1,0 +1,531 @@
+"""Prefill / append attention operators: ``single_prefill_with_kv_cache`` and
+``BatchPrefillWithPagedKVCacheWrapper`` (plan / run split).
+
+Same names, arguments and defaults as the reference's ``flashinfer/prefill.py`` (single :960-1194;
+wrapper :1226-2238).  The kernels are csrc/prefill_kernel.h (MFMA flash attention, GQA-packed tiles);
+there is one backend, so ``backend`` accepts ``auto`` / ``fa2`` / ``fa3`` and means the same thing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import math
+from typing import Any, List, Optional, Tuple, Union
+
+import torch
+
+from . import _lib
+from .page import get_seq_lens
+from .utils import (
+    MaskMode,
+    PosEncodingMode,
+    _check_cached_qkv_data_type,
+    _check_kv_layout,
+    _check_pos_encoding_mode,
+    _get_cache_alibi_slopes_buf,
+    _get_cache_buf,
+    _unpack_paged_kv_cache,
+    canonicalize_torch_dtype,
+    check_shape_dtype_device,
+    is_float8,
+    paged_kv_strides,
+)
+
+
+def _scale_tensor(x, n: int, device) -> Optional[torch.Tensor]:
+    """per-head fp8 scale as a float32 device tensor of n entries (None stays None)."""
+    if x is None:
+        return None
+    if not torch.is_tensor(x):
+        x = torch.full((n,), float(x), dtype=torch.float32)
+    x = x.to(device=device, dtype=torch.float32).contiguous()
+    if x.numel() == 1 and n != 1:
+        x = x.expand(n).contiguous()
+    if x.numel() != n:
+        raise ValueError(f"scale tensor must have {n} entries, got {x.numel()}")
+    return x
+
+
+def single_prefill_with_kv_cache(
+    q: torch.Tensor,
+    k: torch.Tensor,
+    v: torch.Tensor,
+    scale_q: Optional[torch.Tensor] = None,
+    scale_k: Optional[torch.Tensor] = None,
+    scale_v: Optional[torch.Tensor] = None,
+    o_dtype: Optional[torch.dtype] = None,
+    custom_mask: Optional[torch.Tensor] = None,
+    packed_custom_mask: Optional[torch.Tensor] = None,
+    causal: bool = False,
+    kv_layout: str = "NHD",
+    pos_encoding_mode: str = "NONE",
+    use_fp16_qk_reduction: bool = False,
+    sm_scale: Optional[float] = None,
+    window_left: int = -1,
+    logits_soft_cap: Optional[float] = None,
+    rope_scale: Optional[float] = None,
+    rope_theta: Optional[float] = None,
+    backend: str = "auto",
+    return_lse: bool = False,
+) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+    r"""Prefill / append attention with KV cache for a single request.
+
+    Parameters
+    ----------
+    q : ``[qo_len, num_qo_heads, head_dim]``
+    k, v : ``[kv_len, num_kv_heads, head_dim]`` (``NHD``) or ``[num_kv_heads, kv_len, head_dim]`` (``HND``)
+    scale_q, scale_k, scale_v : per-head scales (``[num_qo_heads]`` / ``[num_kv_heads]``) for fp8 inputs
+    o_dtype : output dtype (required for fp8 attention; defaults to ``q.dtype``)
+    causal : apply the causal mask (query i sees keys up to ``i + kv_len - qo_len``)
+    pos_encoding_mode : ``NONE`` / ``ROPE_LLAMA`` (applied in-kernel) / ``ALIBI``
+    sm_scale, window_left, logits_soft_cap, rope_scale, rope_theta : as the reference
+    return_lse : also return the base-2 logsumexp, shape ``[qo_len, num_qo_heads]``
+
+    Custom masks are not implemented in this build (ValueError).  (ref: flashinfer/prefill.py:960-1194)
+    """
+    _check_pos_encoding_mode(pos_encoding_mode)
+    _check_kv_layout(kv_layout)
+    if custom_mask is not None or packed_custom_mask is not None:
+        raise ValueError("custom masks are not supported by the MI355X backend yet")
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        _lib.require_gpu_tensor(t, name)
+    if q.dim() != 3 or k.dim() != 3 or k.shape != v.shape:
+        raise ValueError("q must be [qo_len, num_qo_heads, head_dim]; k, v 3-D with equal shapes")
+    if logits_soft_cap is None:
+        logits_soft_cap = 0.0
+    if sm_scale is None:
+        sm_scale = 1.0 / math.sqrt(q.size(-1))
+    if rope_scale is None:
+        rope_scale = 1.0
+    if rope_theta is None:
+        rope_theta = 1e4
+    qo_len, num_qo_heads, head_dim = q.shape
+    if kv_layout == "NHD":
+        kv_len, num_kv_heads = k.shape[0], k.shape[1]
+        stride_n, stride_h = k.stride(0), k.stride(1)
+    else:
+        num_kv_heads, kv_len = k.shape[0], k.shape[1]
+        stride_h, stride_n = k.stride(0), k.stride(1)
+    if k.stride() != v.stride() or k.stride(-1) != 1 or q.stride(-1) != 1:
+        raise ValueError("k and v must share strides and q/k/v must be contiguous in head_dim")
+    if is_float8(q):
+        assert window_left == -1
+        assert q.dtype == k.dtype == v.dtype
+        scale_q = _scale_tensor(1.0 if scale_q is None else scale_q, num_qo_heads, q.device)
+        scale_k = _scale_tensor(1.0 if scale_k is None else scale_k, num_kv_heads, q.device)
+        scale_v = _scale_tensor(1.0 if scale_v is None else scale_v, num_kv_heads, q.device)
+        if o_dtype is None:
+            raise ValueError("o_dtype should be provided for FP8 attention")
+    else:
+        scale_q = scale_k = scale_v = None
+    if o_dtype is None:
+        o_dtype = q.dtype
+    out = torch.empty(q.shape[:-1] + v.shape[-1:], dtype=o_dtype, device=q.device)
+    lse = None
+    if return_lse:
+        lse = torch.empty((qo_len, num_qo_heads), dtype=torch.float32, device=q.device)
+    alibi = _get_cache_alibi_slopes_buf(num_qo_heads, q.device) if pos_encoding_mode == "ALIBI" else None
+    params = _lib.SinglePrefillParams(
+        q=q.data_ptr(), q_stride_n=q.stride(0), q_stride_h=q.stride(1), k=k.data_ptr(), v=v.data_ptr(),
+        kv_stride_n=stride_n, kv_stride_h=stride_h, o=out.data_ptr(), lse=_lib.ptr(lse),
+        alibi_slopes=_lib.ptr(alibi), scale_q=_lib.ptr(scale_q), scale_k=_lib.ptr(scale_k),
+        scale_v=_lib.ptr(scale_v), qo_len=qo_len, kv_len=kv_len, num_qo_heads=num_qo_heads,
+        num_kv_heads=num_kv_heads, head_dim=head_dim, q_dtype=_lib.fi_dtype(q.dtype),
+        kv_dtype=_lib.fi_dtype(k.dtype), o_dtype=_lib.fi_dtype(o_dtype),
+        mask_mode=MaskMode.CAUSAL.value if causal else MaskMode.NON_CAUSAL.value,
+        pos_encoding_mode=PosEncodingMode[pos_encoding_mode].value, window_left=window_left,
+        logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
+        rope_rcp_theta=1.0 / rope_theta,
+    )
+    with torch.cuda.device(q.device):
+        _lib.check(
+            _lib.lib().fi_single_prefill_run(C.byref(params), None, 0, _lib.current_stream(q.device)),
+            "single_prefill_with_kv_cache",
+        )
+    return (out, lse) if return_lse else out
+
+
+single_prefill_with_kv_cache_return_lse = functools.partial(
+    single_prefill_with_kv_cache, return_lse=True
+)
+
+
+class BatchPrefillWithPagedKVCacheWrapper:
+    r"""Prefill / append attention over a paged KV cache for a batch of requests.
+
+    >>> prefill_wrapper = flashinfer.BatchPrefillWithPagedKVCacheWrapper(workspace_buffer, "NHD")
+    >>> prefill_wrapper.plan(qo_indptr, paged_kv_indptr, paged_kv_indices, paged_kv_last_page_len,
+    ...                      num_qo_heads, num_kv_heads, head_dim, page_size, causal=True)
+    >>> o = prefill_wrapper.run(q, kv_cache)          # [qo_indptr[-1], num_qo_heads, head_dim]
+
+    (ref: flashinfer/prefill.py:1226-2238; example page table :1247-1259)
+    """
+
+    def __init__(
+        self,
+        float_workspace_buffer: torch.Tensor,
+        kv_layout: str = "NHD",
+        use_cuda_graph: bool = False,
+        qo_indptr_buf: Optional[torch.Tensor] = None,
+        paged_kv_indptr_buf: Optional[torch.Tensor] = None,
+        paged_kv_indices_buf: Optional[torch.Tensor] = None,
+        paged_kv_last_page_len_buf: Optional[torch.Tensor] = None,
+        custom_mask_buf: Optional[torch.Tensor] = None,
+        mask_indptr_buf: Optional[torch.Tensor] = None,
+        backend: str = "auto",
+        jit_args: Optional[List[Any]] = None,
+        jit_kwargs: Optional[dict] = None,
+    ) -> None:
+        _check_kv_layout(kv_layout)
+        if jit_args is not None:
+            raise ValueError("jit_args is not supported: kernels are built ahead of time")
+        if backend not in ("auto", "fa2", "fa3"):
+            raise ValueError(f"backend {backend!r} is not available on MI355X (use 'auto')")
+        _lib.require_gpu_tensor(float_workspace_buffer, "float_workspace_buffer")
+        self._kv_layout = kv_layout
+        self._float_workspace_buffer = float_workspace_buffer
+        self.device = float_workspace_buffer.device
+        self._int_workspace_buffer = torch.empty((8 * 1024 * 1024,), dtype=torch.uint8, device=self.device)
+        self._pin_memory_int_workspace_buffer = torch.empty(
+            self._int_workspace_buffer.shape, dtype=torch.uint8, pin_memory=True, device="cpu"
+        )
+        self._use_cuda_graph = use_cuda_graph
+        if use_cuda_graph:
+            for buf, name in ((qo_indptr_buf, "qo_indptr_buf"), (paged_kv_indptr_buf, "paged_kv_indptr_buf"),
+                              (paged_kv_indices_buf, "paged_kv_indices_buf"),
+                              (paged_kv_last_page_len_buf, "paged_kv_last_page_len_buf")):
+                if not torch.is_tensor(buf):
+                    raise ValueError(f"{name} should be a torch.Tensor in CUDA graph mode")
+            self._fixed_batch_size = len(qo_indptr_buf) - 1
+            if len(paged_kv_indptr_buf) != self._fixed_batch_size + 1:
+                raise ValueError("The length of paged_kv_indptr_buf should be batch_size + 1.")
+            if len(paged_kv_last_page_len_buf) != self._fixed_batch_size:
+                raise ValueError("The length of paged_kv_last_page_len_buf should be batch_size.")
+        else:
+            self._fixed_batch_size = 0
+        self._qo_indptr_buf = qo_indptr_buf
+        self._paged_kv_indptr_buf = paged_kv_indptr_buf
+        self._paged_kv_indices_buf = paged_kv_indices_buf
+        self._paged_kv_last_page_len_buf = paged_kv_last_page_len_buf
+        self._backend = backend
+        self._plan_info = None
+
+    @property
+    def is_cuda_graph_enabled(self) -> bool:
+        return self._use_cuda_graph
+
+    def reset_workspace_buffer(
+        self, float_workspace_buffer: torch.Tensor, int_workspace_buffer: torch.Tensor
+    ) -> None:
+        self._float_workspace_buffer = float_workspace_buffer
+        self._int_workspace_buffer = int_workspace_buffer
+        self._pin_memory_int_workspace_buffer = torch.empty(
+            self._int_workspace_buffer.shape, dtype=self._int_workspace_buffer.dtype, device="cpu",
+            pin_memory=True,
+        )
+
+    def plan(
+        self,
+        qo_indptr: torch.Tensor,
+        paged_kv_indptr: torch.Tensor,
+        paged_kv_indices: torch.Tensor,
+        paged_kv_last_page_len: torch.Tensor,
+        num_qo_heads: int,
+        num_kv_heads: int,
+        head_dim_qk: int,
+        page_size: int,
+        head_dim_vo: Optional[int] = None,
+        custom_mask: Optional[torch.Tensor] = None,
+        packed_custom_mask: Optional[torch.Tensor] = None,
+        causal: bool = False,
+        pos_encoding_mode: str = "NONE",
+        use_fp16_qk_reduction: bool = False,
+        sm_scale: Optional[float] = None,
+        window_left: int = -1,
+        logits_soft_cap: Optional[float] = None,
+        rope_scale: Optional[float] = None,
+        rope_theta: Optional[float] = None,
+        q_data_type: Union[str, torch.dtype] = "float16",
+        kv_data_type: Optional[Union[str, torch.dtype]] = None,
+        non_blocking: bool = True,
+        prefix_len_ptr: Optional[torch.Tensor] = None,
+        token_pos_in_items_ptr: Optional[torch.Tensor] = None,
+        token_pos_in_items_len: int = 0,
+        max_item_len_ptr: Optional[torch.Tensor] = None,
+        seq_lens: Optional[torch.Tensor] = None,
+        seq_lens_q: Optional[torch.Tensor] = None,
+        block_tables: Optional[torch.Tensor] = None,
+        max_token_per_sequence: Optional[int] = None,
+        max_sequence_kv: Optional[int] = None,
+        fixed_split_size: Optional[int] = None,
+        disable_split_kv: bool = False,
+        o_data_type: Optional[Union[str, torch.dtype]] = None,
+    ) -> None:
+        r"""Plan batch prefill/append attention for the given ragged queries and page table.
+
+        qo_indptr : ``[batch_size + 1]`` int32; paged_kv_indptr / indices / last_page_len as in decode.
+        causal, pos_encoding_mode, sm_scale, window_left, logits_soft_cap, rope_* configure the variant.
+        q_data_type / kv_data_type : dtypes the run() tensors will have (fp8 e4m3 for both = fp8 attention).
+        o_data_type : (extension) output dtype; defaults to the q dtype, or bfloat16 for fp8 queries.
+        Custom masks and multi-item scoring are not implemented (ValueError).
+        (ref: flashinfer/prefill.py:1523-1921)
+        """
+        if custom_mask is not None or packed_custom_mask is not None:
+            raise ValueError("custom masks are not supported by the MI355X backend yet")
+        if prefix_len_ptr is not None or token_pos_in_items_ptr is not None or max_item_len_ptr is not None:
+            raise ValueError("multi-item scoring is not supported by the MI355X backend")
+        for tensor, name in [(qo_indptr, "qo_indptr"), (paged_kv_indptr, "paged_kv_indptr"),
+                             (paged_kv_indices, "paged_kv_indices"),
+                             (paged_kv_last_page_len, "paged_kv_last_page_len")]:
+            if tensor.dtype != torch.int32:
+                raise ValueError(f"{name} must have dtype torch.int32, got {tensor.dtype}")
+        _check_pos_encoding_mode(pos_encoding_mode)
+        q_data_type = canonicalize_torch_dtype(q_data_type)
+        if kv_data_type is None:
+            kv_data_type = q_data_type
+        kv_data_type = canonicalize_torch_dtype(kv_data_type)
+        if o_data_type is None:
+            o_data_type = torch.bfloat16 if q_data_type in (torch.float8_e4m3fn, torch.float8_e5m2) else q_data_type
+        o_data_type = canonicalize_torch_dtype(o_data_type)
+        if logits_soft_cap is None:
+            logits_soft_cap = 0.0
+        if head_dim_vo is None:
+            head_dim_vo = head_dim_qk
+        batch_size = len(qo_indptr) - 1
+        if len(paged_kv_indptr) != batch_size + 1 or len(paged_kv_last_page_len) != batch_size:
+            raise ValueError("qo_indptr, paged_kv_indptr and paged_kv_last_page_len disagree on the batch size")
+
+        qo_indptr_host = qo_indptr.to("cpu").contiguous()
+        paged_kv_indptr_host = paged_kv_indptr.to("cpu").contiguous()
+        paged_kv_last_page_len_host = paged_kv_last_page_len.to("cpu")
+        if seq_lens is None:
+            kv_lens_arr_host = get_seq_lens(paged_kv_indptr_host, paged_kv_last_page_len_host, page_size)
+        else:
+            kv_lens_arr_host = seq_lens.cpu()
+        kv_lens_arr_host = kv_lens_arr_host.to(torch.int32).contiguous()
+        total_num_rows = int(qo_indptr_host[-1])
+
+        if self.is_cuda_graph_enabled:
+            if batch_size != self._fixed_batch_size:
+                raise ValueError(
+                    "The batch size should be fixed during the lifecycle of the wrapper in cuda graph mode, "
+                    f"the runtime batch size {batch_size} mismatches the batch size {self._fixed_batch_size}"
+                )
+            if len(paged_kv_indices) > len(self._paged_kv_indices_buf):
+                raise ValueError("The length of paged_kv_indices exceeds the allocated buffer size.")
+            self._qo_indptr_buf.copy_(qo_indptr, non_blocking=non_blocking)
+            self._paged_kv_indptr_buf.copy_(paged_kv_indptr, non_blocking=non_blocking)
+            self._paged_kv_last_page_len_buf.copy_(paged_kv_last_page_len, non_blocking=non_blocking)
+            self._paged_kv_indices_buf[: len(paged_kv_indices)].copy_(
+                paged_kv_indices, non_blocking=(paged_kv_indices.device == self.device) and non_blocking
+            )
+            if max_token_per_sequence is None:
+                total_rows_bound = total_num_rows
+            else:
+                total_rows_bound = max_token_per_sequence * batch_size
+        else:
+            self._qo_indptr_buf = qo_indptr.to(self.device, non_blocking=non_blocking)
+            self._paged_kv_indptr_buf = paged_kv_indptr.to(self.device, non_blocking=non_blocking)
+            self._paged_kv_indices_buf = paged_kv_indices.to(self.device, non_blocking=non_blocking)
+            self._paged_kv_last_page_len_buf = paged_kv_last_page_len.to(self.device, non_blocking=non_blocking)
+            total_rows_bound = total_num_rows
+
+        plan_info = (C.c_int64 * _lib.FI_PREFILL_PLAN_INFO_LEN)()
+        with torch.cuda.device(self.device):
+            _lib.check(
+                _lib.lib().fi_batch_prefill_plan(
+                    self._float_workspace_buffer.data_ptr(),
+                    self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size(),
+                    self._int_workspace_buffer.data_ptr(),
+                    self._pin_memory_int_workspace_buffer.data_ptr(),
+                    self._int_workspace_buffer.numel(),
+                    qo_indptr_host.data_ptr(), paged_kv_indptr_host.data_ptr(), kv_lens_arr_host.data_ptr(),
+                    total_rows_bound, batch_size, num_qo_heads, num_kv_heads, page_size,
+                    int(self.is_cuda_graph_enabled), head_dim_qk, head_dim_vo, int(causal), window_left,
+                    -1 if fixed_split_size is None else fixed_split_size, int(disable_split_kv),
+                    plan_info, _lib.current_stream(self.device),
+                ),
+                "BatchPrefillWithPagedKVCacheWrapper.plan",
+            )
+        self._plan_info = list(plan_info)
+        self._plan_info_c = plan_info
+        self._batch_size = batch_size
+        self._num_qo_heads = num_qo_heads
+        self._num_kv_heads = num_kv_heads
+        self._head_dim = head_dim_qk
+        self._page_size = page_size
+        self._total_num_rows = total_num_rows
+        self._cached_q_data_type = q_data_type
+        self._cached_kv_data_type = kv_data_type
+        self._cached_o_data_type = o_data_type
+        self._causal = causal
+        self._pos_encoding_mode = pos_encoding_mode
+        self._window_left = window_left
+        self._logits_soft_cap = logits_soft_cap
+        self._sm_scale = sm_scale
+        self._rope_scale = rope_scale
+        self._rope_theta = rope_theta
+
+    begin_forward = plan
+
+    def forward(self, q, paged_kv_cache, causal=False, pos_encoding_mode="NONE", use_fp16_qk_reduction=False,
+                k_scale=None, v_scale=None, window_left=-1, logits_soft_cap=None, sm_scale=None,
+                rope_scale=None, rope_theta=None) -> torch.Tensor:
+        r"""Warning: This function is deprecated, please use :meth:`run` instead."""
+        self._causal = causal
+        self._pos_encoding_mode = pos_encoding_mode
+        self._window_left = window_left
+        self._logits_soft_cap = logits_soft_cap
+        self._sm_scale = sm_scale
+        self._rope_scale = rope_scale
+        self._rope_theta = rope_theta
+        return self.run(q, paged_kv_cache, k_scale=k_scale, v_scale=v_scale)
+
+    def run(
+        self,
+        q: torch.Tensor,
+        paged_kv_cache: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]],
+        *args,
+        q_scale: Optional[float] = None,
+        k_scale: Optional[float] = None,
+        v_scale: Optional[float] = None,
+        out: Optional[torch.Tensor] = None,
+        lse: Optional[torch.Tensor] = None,
+        return_lse: bool = False,
+        enable_pdl: Optional[bool] = None,
+        window_left: Optional[int] = None,
+        sinks: Optional[torch.Tensor] = None,
+        scale_q: Optional[torch.Tensor] = None,
+        scale_k: Optional[torch.Tensor] = None,
+        scale_v: Optional[torch.Tensor] = None,
+    ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        r"""Compute batch prefill/append attention between ``q`` and the paged KV cache.
+
+        q : ``[qo_indptr[-1], num_qo_heads, head_dim]``; paged_kv_cache as in decode.
+        q_scale / k_scale / v_scale : scalar calibration scales (folded into sm_scale / the output).
+        scale_q / scale_k / scale_v : (extension) per-head fp8 scales ``[num_qo_heads]`` / ``[num_kv_heads]``
+            for fp8 attention (the reference's FA3 kernel takes them, csrc/batch_prefill_fp8_sm90.cu:81-185,
+            but its wrapper passes None).
+        Returns ``[qo_indptr[-1], num_qo_heads, head_dim]`` (+ base-2 logsumexp ``[nnz, num_qo_heads]``).
+        (ref: flashinfer/prefill.py:1979-2206)
+        """
+        if self._plan_info is None:
+            raise RuntimeError("plan() must be called before run()")
+        if sinks is not None:
+            raise ValueError("attention sinks are not supported by this backend")
+        if args:
+            raise ValueError("additional kernel arguments require jit_args, which is not supported")
+        _lib.require_gpu_tensor(q, "q")
+        k_cache, v_cache = _unpack_paged_kv_cache(paged_kv_cache, self._kv_layout)
+        _check_cached_qkv_data_type(q, k_cache, self._cached_q_data_type, self._cached_kv_data_type)
+        page_size, num_kv_heads, head_dim, stride_page, stride_n, stride_h = paged_kv_strides(
+            k_cache, v_cache, self._kv_layout
+        )
+        window_left = self._window_left if window_left is None else window_left
+        assert window_left == self._window_left
+        logits_soft_cap = self._logits_soft_cap
+        sm_scale = self._sm_scale
+        rope_scale = self._rope_scale
+        rope_theta = self._rope_theta
+        if logits_soft_cap is None:
+            logits_soft_cap = 0.0
+        if sm_scale is None:
+            sm_scale = 1.0 / math.sqrt(q.size(-1))
+        if q_scale is not None:
+            sm_scale *= q_scale
+        if k_scale is not None:
+            sm_scale *= k_scale
+        if rope_scale is None:
+            rope_scale = 1.0
+        if rope_theta is None:
+            rope_theta = 1e4
+        if q.dim() != 3 or q.shape[0] != self._total_num_rows or q.shape[1] != self._num_qo_heads:
+            raise ValueError(
+                f"q must have shape [{self._total_num_rows}, {self._num_qo_heads}, head_dim], got {tuple(q.shape)}"
+            )
+        if q.shape[2] != head_dim or head_dim != self._head_dim:
+            raise ValueError("head_dim of q / kv cache does not match the planned head_dim")
+        if num_kv_heads != self._num_kv_heads or page_size != self._page_size:
+            raise ValueError("kv cache shape does not match the planned num_kv_heads / page_size")
+        if q.stride(-1) != 1:
+            q = q.contiguous()
+        o_dtype = self._cached_o_data_type
+        if return_lse:
+            if lse is None:
+                lse = torch.empty((q.size(0), q.size(1)), dtype=torch.float32, device=q.device)
+            else:
+                check_shape_dtype_device(lse, (q.size(0), q.size(1)), torch.float32, q.device, "lse")
+        out_shape = q.shape[:-1] + v_cache.shape[-1:]
+        if out is None:
+            out = torch.empty(out_shape, dtype=o_dtype, device=q.device)
+        else:
+            check_shape_dtype_device(out, out_shape, o_dtype, q.device, "out")
+            if not out.is_contiguous():
+                raise ValueError("out must be contiguous")
+        fp8_q = is_float8(q)
+        if fp8_q:
+            scale_q = _scale_tensor(1.0 if scale_q is None else scale_q, self._num_qo_heads, q.device)
+            scale_k = _scale_tensor(1.0 if scale_k is None else scale_k, num_kv_heads, q.device)
+            scale_v = _scale_tensor(1.0 if scale_v is None else scale_v, num_kv_heads, q.device)
+        else:
+            scale_q = _scale_tensor(scale_q, self._num_qo_heads, q.device)
+            scale_k = _scale_tensor(scale_k, num_kv_heads, q.device)
+            scale_v = _scale_tensor(scale_v, num_kv_heads, q.device)
+        alibi = None
+        if self._pos_encoding_mode == "ALIBI":
+            alibi = _get_cache_alibi_slopes_buf(q.shape[1], q.device)
+        params = _lib.BatchPrefillParams(
+            q=q.data_ptr(), q_stride_n=q.stride(0), q_stride_h=q.stride(1),
+            qo_indptr=self._qo_indptr_buf.data_ptr(),
+            kv=_lib.PagedKV(
+                k_data=k_cache.data_ptr(), v_data=v_cache.data_ptr(),
+                indptr=self._paged_kv_indptr_buf.data_ptr(), indices=self._paged_kv_indices_buf.data_ptr(),
+                last_page_len=self._paged_kv_last_page_len_buf.data_ptr(), rope_pos_offset=None,
+                stride_page=stride_page, stride_n=stride_n, stride_h=stride_h, page_size=page_size,
+                num_kv_heads=num_kv_heads, head_dim=head_dim, batch_size=self._batch_size,
+                dtype=_lib.fi_dtype(k_cache.dtype),
+            ),
+            o=out.data_ptr(), lse=_lib.ptr(lse) if return_lse else None, alibi_slopes=_lib.ptr(alibi),
+            scale_q=_lib.ptr(scale_q), scale_k=_lib.ptr(scale_k), scale_v=_lib.ptr(scale_v),
+            num_qo_heads=self._num_qo_heads, q_dtype=_lib.fi_dtype(q.dtype), o_dtype=_lib.fi_dtype(o_dtype),
+            mask_mode=MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value,
+            pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=window_left,
+            logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
+            rope_rcp_theta=1.0 / rope_theta,
+        )
+        with torch.cuda.device(q.device):
+            _lib.check(
+                _lib.lib().fi_batch_prefill_paged_run(
+                    self._float_workspace_buffer.data_ptr(),
+                    self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size(),
+                    self._int_workspace_buffer.data_ptr(), self._int_workspace_buffer.numel(),
+                    self._plan_info_c, _lib.FI_PREFILL_PLAN_INFO_LEN, C.byref(params),
+                    _lib.current_stream(q.device),
+                ),
+                "BatchPrefillWithPagedKVCacheWrapper.run",
+            )
+        if v_scale is not None:
+            if is_float8(out):
+                out = (out.to(torch.float32) * v_scale).to(out.dtype)
+            else:
+                out *= v_scale
+        return (out, lse) if return_lse else out
+
+    run_return_lse = functools.partialmethod(run, return_lse=True)
+
+    def forward_return_lse(self, q, paged_kv_cache, causal=False, pos_encoding_mode="NONE",
+                           use_fp16_qk_reduction=False, k_scale=None, v_scale=None, window_left=-1,
+                           logits_soft_cap=None, sm_scale=None, rope_scale=None, rope_theta=None):
+        r"""Warning: This function is deprecated, please use :meth:`run_return_lse` instead."""
+        self._causal = causal
+        self._pos_encoding_mode = pos_encoding_mode
+        self._window_left = window_left
+        self._logits_soft_cap = logits_soft_cap
+        self._sm_scale = sm_scale
+        self._rope_scale = rope_scale
+        self._rope_theta = rope_theta
+        return self.run_return_lse(q, paged_kv_cache, k_scale=k_scale, v_scale=v_scale)
+
+    def end_forward(self) -> None:
+        r"""Warning: this function is deprecated and has no effect."""
+        pass

@@ -195,6 +195,83 @@ FI_API int fi_variable_length_merge_states(const void* v, const float* s, const 
                                     int32_t num_heads, int32_t head_dim, int32_t in_dtype,
                                     int32_t out_dtype, fi_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch prefill / append attention over a paged KV cache.
+ * ref: BatchPrefillWithKVCachePlan csrc/batch_prefill.cu:47-74, BatchPrefillWithPagedKVCacheRun
+ * csrc/batch_prefill.cu:199-327; fp8: csrc/batch_prefill_fp8_sm90.cu:39-67, 81-185; planner
+ * PrefillPlan include/flashinfer/attention/scheduler.cuh:694-795.
+ * ---------------------------------------------------------------------------------------------- */
+#define FI_PREFILL_PLAN_INFO_LEN 16
+enum fi_prefill_plan_slot {
+  FI_PP_PADDED_BATCH_SIZE = 0, /* work items launched (q tiles over all requests) */
+  FI_PP_TOTAL_NUM_ROWS = 1,
+  FI_PP_CTA_TILE_Q = 3,
+  FI_PP_REQUEST_INDICES_OFFSET = 4,
+  FI_PP_QO_TILE_INDICES_OFFSET = 5,
+  FI_PP_ENABLE_CUDA_GRAPH = 13,
+  FI_PP_SPLIT_KV = 14,
+  FI_PP_MAGIC = 15
+};
+#define FI_PREFILL_PLAN_MAGIC 0x4649505245ll /* "FIPRE" */
+
+/* qo_indptr_h / kv_indptr_h: HOST [batch+1]; kv_len_arr_h: HOST [batch]. int_ws == NULL plans on the
+ * host only.  fixed_split_size / disable_split_kv are accepted for API parity (this build never splits
+ * the kv axis of a prefill work item, so results are batch-invariant by construction). */
+FI_API int fi_batch_prefill_plan(void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws,
+                          size_t int_ws_bytes, const int32_t* qo_indptr_h, const int32_t* kv_indptr_h,
+                          const int32_t* kv_len_arr_h, int32_t total_num_rows, int32_t batch_size,
+                          int32_t num_qo_heads, int32_t num_kv_heads, int32_t page_size,
+                          int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
+                          int32_t causal, int32_t window_left, int32_t fixed_split_size,
+                          int32_t disable_split_kv, int64_t* plan_info_out, fi_stream_t stream);
+
+typedef struct fi_batch_prefill_params {
+  const void* q; /* [nnz_qo, num_qo_heads, head_dim] */
+  int64_t q_stride_n, q_stride_h;
+  const int32_t* qo_indptr; /* [batch+1] device */
+  fi_paged_kv_t kv;
+  void* o;    /* [nnz_qo, num_qo_heads, head_dim] contiguous */
+  float* lse; /* optional [nnz_qo, num_qo_heads] */
+  const float* alibi_slopes;
+  const float* scale_q; /* fp8 path: [num_qo_heads] (NULL = 1) */
+  const float* scale_k; /* [num_kv_heads] */
+  const float* scale_v; /* [num_kv_heads] */
+  int32_t num_qo_heads;
+  int32_t q_dtype; /* f16 / bf16 / fp8_e4m3 (then kv must be fp8_e4m3 too) */
+  int32_t o_dtype; /* f16 / bf16 */
+  int32_t mask_mode; /* fi_mask_mode: NON_CAUSAL / CAUSAL */
+  int32_t pos_encoding_mode;
+  int32_t window_left;
+  float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
+} fi_batch_prefill_params_t;
+
+FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws_bytes, void* int_ws, size_t int_ws_bytes,
+                               const int64_t* plan_info, int32_t plan_info_len,
+                               const fi_batch_prefill_params_t* params, fi_stream_t stream);
+
+/* Single-request prefill over dense K/V.  ref: csrc/single_prefill.cu, flashinfer/prefill.py:960-1194. */
+typedef struct fi_single_prefill_params {
+  const void* q; /* [qo_len, num_qo_heads, head_dim] */
+  int64_t q_stride_n, q_stride_h;
+  const void* k; /* [kv_len, H, D] (NHD) or [H, kv_len, D] (HND) by strides */
+  const void* v;
+  int64_t kv_stride_n, kv_stride_h;
+  void* o;
+  float* lse;
+  const float* alibi_slopes;
+  const float* scale_q;
+  const float* scale_k;
+  const float* scale_v;
+  int32_t qo_len, kv_len, num_qo_heads, num_kv_heads, head_dim;
+  int32_t q_dtype, kv_dtype, o_dtype;
+  int32_t mask_mode, pos_encoding_mode, window_left;
+  float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
+} fi_single_prefill_params_t;
+
+FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* params, void* tmp, size_t tmp_bytes,
+                          fi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

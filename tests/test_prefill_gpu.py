@@ -1,0 +1,191 @@
+"""GPU parity: MFMA prefill kernels (through the C ABI) against the CPU oracle.  Grid modelled on the
+reference's tests/attention/test_batch_prefill_kernels.py:228-279, test_single_prefill.py:56-100,
+test_fp8_prefill.py:23-191 and test_hopper_fp8_attention.py:64-108."""
+import pytest
+import torch
+
+from oracle import attention_ref as R
+from test_decode_gpu import make_paged, tol
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run_batch_prefill(q, qo_lens, cache, layout, indptr, indices, last, hq, hkv, d, ps, **plan_kw):
+    import flashinfer
+
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, layout)
+    w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps,
+           q_data_type=q.dtype, kv_data_type=cache.dtype, **plan_kw)
+    o, lse = w.run(q.to(DEV), cache.to(DEV), return_lse=True)
+    return o, lse, qo_indptr
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("hq,hkv", [(4, 4), (8, 2), (28, 4)])
+@pytest.mark.parametrize("d,ps,layout", [(128, 16, "NHD"), (128, 1, "HND"), (64, 8, "NHD")])
+def test_batch_prefill_matches_oracle(dtype, causal, hq, hkv, d, ps, layout):
+    kv_lens = [54, 300, 1, 129, 17]
+    qo_lens = [37, 300, 1, 17, 0]  # append (qo < kv), full prefill, single row, empty request
+    torch.manual_seed(1)
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, ps, hkv, d, dtype, layout, seed=21)
+    q = torch.randn(sum(qo_lens), hq, d).to(dtype)
+    o, lse, qo_indptr = run_batch_prefill(q, qo_lens, cache, layout, indptr, indices, last, hq, hkv, d, ps,
+                                          causal=causal)
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), layout, indptr, indices, last,
+                                         causal=causal)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), **tol(dtype))
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("qo_len,kv_len", [(1, 1), (15, 127), (128, 128), (129, 257), (513, 700), (1000, 1000)])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("layout", ["NHD", "HND"])
+def test_single_prefill_matches_oracle(qo_len, kv_len, causal, layout):
+    # ref: tests/attention/test_single_prefill.py (seed 0)
+    import flashinfer
+
+    torch.manual_seed(0)
+    hq, hkv, d = 8, 2, 128
+    q = torch.randn(qo_len, hq, d).half()
+    shape = (kv_len, hkv, d) if layout == "NHD" else (hkv, kv_len, d)
+    k, v = torch.randn(shape).half(), torch.randn(shape).half()
+    o, lse = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal,
+                                                     kv_layout=layout, return_lse=True)
+    kk, vv = (k, v) if layout == "NHD" else (k.transpose(0, 1), v.transpose(0, 1))
+    o_ref, lse_ref = R.attention_ref(q.float(), kk.float(), vv.float(), causal=causal)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("kw", [dict(pos_encoding_mode="ROPE_LLAMA"), dict(pos_encoding_mode="ALIBI"),
+                                dict(logits_soft_cap=20.0), dict(window_left=33), dict(sm_scale=0.05)])
+def test_single_prefill_variants(kw):
+    import flashinfer
+
+    torch.manual_seed(4)
+    qo_len, kv_len, hq, hkv, d = 150, 333, 8, 4, 128
+    q = torch.randn(qo_len, hq, d).half()
+    k, v = torch.randn(kv_len, hkv, d).half(), torch.randn(kv_len, hkv, d).half()
+    o, lse = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), causal=True,
+                                                     return_lse=True, **kw)
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), causal=True, **kw)
+    # fused RoPE rounds the rotated q/k to fp16 before QK^T as the reference does (prefill.cuh:465-612)
+    t = 3e-3 if kw.get("pos_encoding_mode") == "ROPE_LLAMA" else 1e-3
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=t, atol=t)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=t, atol=5 * t)
+
+
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_batch_prefill_fp8_kv_cache(kv_dtype):
+    # fp16 queries over an fp8 cache (ref: tests/attention/test_fp8_prefill.py:23-114); the oracle sees the
+    # same quantised cache, so the 16-bit tolerance applies.
+    hq, hkv, d, ps = 8, 2, 128, 16
+    kv_lens, qo_lens = [200, 77], [64, 77]
+    cache, indptr, indices, last = make_paged(2, kv_lens, ps, hkv, d, kv_dtype, "NHD", seed=8)
+    q = torch.randn(sum(qo_lens), hq, d).half()
+    o, lse, qo_indptr = run_batch_prefill(q, qo_lens, cache, "NHD", indptr, indices, last, hq, hkv, d, ps,
+                                          causal=True)
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last,
+                                         causal=True)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("seq_len", [117, 509])
+def test_single_prefill_fp8_qkv(causal, seq_len):
+    """fp8 q/k/v with per-head scales.  Two bars: (1) against the oracle that restates the reference's
+    fp8 arithmetic (P rounded to e4m3) -- rtol = atol = 2e-3 in fp16 output; (2) the reference's own bar,
+    MSE < 1.0 against 16-bit attention (test_hopper_fp8_attention.py:105-108)."""
+    import flashinfer
+
+    torch.manual_seed(2)
+    h, d = 8, 128
+    q, k, v = (torch.randn(seq_len, h, d).half() for _ in range(3))
+    q8, sq = R.per_head_symmetric_quant(q)
+    k8, sk = R.per_head_symmetric_quant(k)
+    v8, sv = R.per_head_symmetric_quant(v)
+    o = flashinfer.single_prefill_with_kv_cache(q8.to(DEV), k8.to(DEV), v8.to(DEV), sq.to(DEV), sk.to(DEV),
+                                                sv.to(DEV), causal=causal, o_dtype=torch.float16)
+    o_ref8, _ = R.fp8_attention_ref(q8, k8, v8, sq, sk, sv, causal=causal)
+    torch.testing.assert_close(o.float().cpu(), o_ref8.float(), rtol=2e-3, atol=2e-3)
+    o_16, _ = R.attention_ref(q.float(), k.float(), v.float(), causal=causal)
+    assert torch.mean((o.float().cpu() - o_16.float()) ** 2) < 1.0
+
+
+def test_batch_prefill_fp8_qkv_paged_c3_shape_small():
+    """BASELINE config C3 semantics at a reduced size: fp8 e4m3 q and paged kv, causal, GQA 32/8, d128."""
+    hq, hkv, d, ps = 32, 8, 128, 16
+    kv_lens, qo_lens = [512, 300], [256, 300]
+    torch.manual_seed(0)
+    kv16 = [torch.randn(l, 2, hkv, d).half() for l in kv_lens]
+    q16 = torch.randn(sum(qo_lens), hq, d).half()
+    q8, sq = R.per_head_symmetric_quant(q16)
+    kcat = torch.cat([x[:, 0] for x in kv16])
+    vcat = torch.cat([x[:, 1] for x in kv16])
+    k8, sk = R.per_head_symmetric_quant(kcat)
+    v8, sv = R.per_head_symmetric_quant(vcat)
+    # build the paged cache from the quantised rows
+    import flashinfer
+
+    pages = [-(-l // ps) for l in kv_lens]
+    total = sum(pages)
+    cache = torch.zeros(total, 2, ps, hkv, d, dtype=torch.float8_e4m3fn)
+    indptr = torch.tensor([0] + list(torch.tensor(pages).cumsum(0)), dtype=torch.int32)
+    indices = torch.randperm(total).to(torch.int32)
+    last = torch.tensor([(l - 1) % ps + 1 for l in kv_lens], dtype=torch.int32)
+    off = 0
+    cache_f = cache.float()
+    for b, l in enumerate(kv_lens):
+        for t in range(l):
+            pg = int(indices[int(indptr[b]) + t // ps])
+            cache_f[pg, 0, t % ps] = k8[off + t].float()
+            cache_f[pg, 1, t % ps] = v8[off + t].float()
+        off += l
+    cache = cache_f.to(torch.float8_e4m3fn)
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, "NHD")
+    w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps, causal=True,
+           q_data_type=torch.float8_e4m3fn, kv_data_type=torch.float8_e4m3fn, o_data_type=torch.bfloat16)
+    o, lse = w.run(q8.to(DEV), cache.to(DEV), return_lse=True, scale_q=sq.to(DEV), scale_k=sk.to(DEV),
+                   scale_v=sv.to(DEV))
+    assert o.dtype == torch.bfloat16
+    off = 0
+    for b in range(2):
+        qs = q8[int(qo_indptr[b]):int(qo_indptr[b + 1])]
+        o_ref, lse_ref = R.fp8_attention_ref(qs, k8[off:off + kv_lens[b]], v8[off:off + kv_lens[b]], sq, sk, sv,
+                                             causal=True)
+        got = o[int(qo_indptr[b]):int(qo_indptr[b + 1])].float().cpu()
+        torch.testing.assert_close(got, o_ref.float(), rtol=2e-3 + 2.0 ** -8, atol=3e-3)
+        torch.testing.assert_close(lse[int(qo_indptr[b]):int(qo_indptr[b + 1])].cpu(), lse_ref.float(),
+                                   rtol=1e-3, atol=2e-3)
+        off += kv_lens[b]
+
+
+def test_prefill_cuda_graph_mode_and_errors():
+    import flashinfer
+
+    hq, hkv, d, ps, b = 8, 2, 128, 16, 3
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(
+        ws, "NHD", use_cuda_graph=True, qo_indptr_buf=torch.empty(b + 1, dtype=torch.int32, device=DEV),
+        paged_kv_indptr_buf=torch.empty(b + 1, dtype=torch.int32, device=DEV),
+        paged_kv_indices_buf=torch.empty(256, dtype=torch.int32, device=DEV),
+        paged_kv_last_page_len_buf=torch.empty(b, dtype=torch.int32, device=DEV))
+    for seed, (kv_lens, qo_lens) in enumerate([([100, 40, 300], [10, 40, 6]), ([5, 500, 64], [5, 16, 35])]):
+        cache, indptr, indices, last = make_paged(b, kv_lens, ps, hkv, d, torch.float16, "NHD", seed=seed)
+        q = torch.randn(56, hq, d).half()
+        qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+        w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, causal=True, max_token_per_sequence=64)
+        o = w.run(q.to(DEV), cache.to(DEV))
+        o_ref, _ = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last, causal=True)
+        torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    with pytest.raises(ValueError):
+        w.plan(qo_indptr.long(), indptr, indices, last, hq, hkv, d, ps)
+    with pytest.raises(ValueError):
+        w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, custom_mask=torch.ones(4, dtype=torch.bool))
