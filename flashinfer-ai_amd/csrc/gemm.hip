@@ -1,0 +1,316 @@
+// fp8 (e4m3 / e5m2) groupwise-scaled GEMM and grouped GEMM for gfx950.
+//
+// What it replaces: the reference's CUTLASS blockwise-scaled kernels
+// (include/flashinfer/gemm/gemm_groupwise_sm100.cuh, group_gemm_fp8_groupwise_sm100.cuh:35-72, 76-250;
+// bindings csrc/gemm_groupwise_sm100.cu:89-120, csrc/group_gemm_fp8_groupwise_sm100.cu:89-124).
+//   D[g] = (A[g] . sA) (B[g] . sB)^T ;  A (cum_m, k) fp8 row-major, B (G, n, k) fp8 ("nt"), f32 accumulate,
+//   scales per (1 or 128 rows of A, 128 k) and per (128 rows of B, 128 k)   (flashinfer/gemm.py:2657-2719).
+//
+// Structure: one workgroup (4 waves) owns a 128 (m) x 128 (n) output tile of one group and walks K in
+// 128-wide blocks = the scale granularity.  A and B tiles are staged through LDS ([128 rows][128 B] fp8
+// images, 16-byte chunks XOR-swizzled so that ds_read_b128 is conflict-free) with register prefetch of the
+// next block.  The product is computed TRANSPOSED (D^T = B A^T, mfma_f32_32x32x16_fp8_fp8): the m index
+// then sits on the lane, so the per-row A scale is one value per lane and the per-block B scale is wave
+// uniform; each K block's partial product is folded into the running f32 accumulator with one fma per
+// element (two-level accumulation, exactly the block-scaled definition).
+#include <string.h>
+
+#include "common.h"
+
+namespace fi {
+
+constexpr int kGemmThreads = 256;
+constexpr int kBM = 128, kBN = 128, kBK = 128;
+
+struct GemmParams {
+  const uint8_t* a;
+  const uint8_t* b;
+  const float* a_scale;
+  const float* b_scale;
+  void* d;
+  const int32_t* m_indptr;  // [G+1] device; NULL: one group of m_total rows
+  int32_t num_groups, m_total, n, k;
+  int32_t a_gran_m;         // 1 or 128
+  int32_t scale_k_major;    // 0: "MN" major, 1: "K" major
+  int32_t out_dtype;
+  int32_t num_m_tiles_bound;  // grid bound on (group, m tile) pairs
+  int32_t n_tiles;
+  int32_t a_is_e5m2, b_is_e5m2;
+};
+
+using f32x16g = __attribute__((ext_vector_type(16))) float;
+
+template <bool A_E5M2, bool B_E5M2>
+__device__ __forceinline__ f32x16g mfma_fp8(long a, long b, f32x16g c) {
+  if constexpr (!A_E5M2 && !B_E5M2) return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
+  else if constexpr (!A_E5M2 && B_E5M2) return __builtin_amdgcn_mfma_f32_32x32x16_fp8_bf8(a, b, c, 0, 0, 0);
+  else if constexpr (A_E5M2 && !B_E5M2) return __builtin_amdgcn_mfma_f32_32x32x16_bf8_fp8(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf8_bf8(a, b, c, 0, 0, 0);
+}
+
+// MA_E5M2 / MB_E5M2 refer to the MFMA A operand (= matrix B of the GEMM) and MFMA B operand (= matrix A)
+template <bool MA_E5M2, bool MB_E5M2>
+__global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2][2][kBM * kBK];  // [stage][A|B]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lq = lane & 31, lh = lane >> 5;
+
+  // ---- tile assignment: XCD-contiguous logical id; n tile fastest so that an A tile is reused ----
+  const int total = p.num_m_tiles_bound * p.n_tiles;
+  int logical;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  const int mt_global = logical / p.n_tiles;
+  const int nt = logical - mt_global * p.n_tiles;
+  // (group, m tile) from the running count of m tiles (ref: arg-prep kernel
+  // group_gemm_fp8_groupwise_sm100.cuh:35-72 computes per-group problem sizes on the device too)
+  int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
+  if (p.m_indptr) {
+    int acc = 0;
+    bool found = false;
+    for (int gi = 0; gi < p.num_groups; ++gi) {
+      const int lo = p.m_indptr[gi], hi = p.m_indptr[gi + 1];
+      const int tiles = (hi - lo + kBM - 1) / kBM;
+      if (!found && mt_global < acc + tiles) {
+        g = gi;
+        m_begin = lo;
+        m_end = hi;
+        mt = mt_global - acc;
+        found = true;
+      }
+      acc += tiles;
+    }
+    if (!found) return;
+  } else if (mt_global * kBM >= p.m_total) {
+    return;
+  }
+  const int m0 = m_begin + mt * kBM;
+  const int n0 = nt * kBN;
+  const int K = p.k, N = p.n;
+  const int kblocks = K / kBK;
+  const uint8_t* Bg = p.b + (int64_t)g * N * K;
+
+  // ---- staging geometry: 4 passes of 32 rows x 8 chunks ----
+  const int st_row = tid >> 3, st_ch = tid & 7;
+  auto lds_off = [](int row, int ch) { return row * kBK + ((ch ^ ((row >> 1) & 7)) << 4); };
+  u32x4 ra[4], rb[4];
+  auto issue = [&](int kb) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 32 + st_row;
+      const int am = min(m0 + row, m_end - 1);
+      const int bn = min(n0 + row, N - 1);
+      ra[ps] = *(const u32x4*)(p.a + (int64_t)am * K + kb * kBK + st_ch * 16);
+      rb[ps] = *(const u32x4*)(Bg + (int64_t)bn * K + kb * kBK + st_ch * 16);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = ps * 32 + st_row;
+      *(u32x4*)(&smem[buf][0][lds_off(row, st_ch)]) = ra[ps];
+      *(u32x4*)(&smem[buf][1][lds_off(row, st_ch)]) = rb[ps];
+    }
+  };
+  // scales: a per lane (its m column), b per workgroup n tile
+  auto a_scale_at = [&](int kb, int m) -> float {
+    const int mi = p.a_gran_m == 1 ? m : m / p.a_gran_m;
+    const int m_cnt = p.a_gran_m == 1 ? p.m_total : (p.m_total + p.a_gran_m - 1) / p.a_gran_m;
+    return p.scale_k_major ? p.a_scale[(int64_t)mi * kblocks + kb] : p.a_scale[(int64_t)kb * m_cnt + mi];
+  };
+  const int n_sblocks = (N + 127) / 128;
+  auto b_scale_at = [&](int kb) -> float {
+    const int nb = n0 / 128;
+    return p.scale_k_major ? p.b_scale[((int64_t)g * n_sblocks + nb) * kblocks + kb]
+                           : p.b_scale[((int64_t)g * kblocks + kb) * n_sblocks + nb];
+  };
+
+  f32x16g acc[2][2];  // [n block][m block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  int m_lane[2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) m_lane[mb] = min(m0 + 64 * wm + 32 * mb + lq, m_end - 1);
+
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int kb = 0; kb < kblocks; ++kb) {
+    const int buf = kb & 1;
+    const bool has_next = kb + 1 < kblocks;
+    if (has_next) issue(kb + 1);
+    float sa[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) sa[mb] = a_scale_at(kb, m_lane[mb]);
+    const float sb = b_scale_at(kb);
+
+    f32x16g part[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {  // 32 bytes of k per step pair: bytes [32 kp + 16 lh, +16)
+      u32x4 fa[2], fb[2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+        fa[mb] = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 2 * kp + lh)]);
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        fb[nb] = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 2 * kp + lh)]);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const long bfrag = (long)fb[nb][2 * half] | ((long)fb[nb][2 * half + 1] << 32);
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb) {
+            const long afrag = (long)fa[mb][2 * half] | ((long)fa[mb][2 * half + 1] << 32);
+            part[nb][mb] = mfma_fp8<MA_E5M2, MB_E5M2>(bfrag, afrag, part[nb][mb]);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const float s = sa[mb] * sb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][mb][r] += s * part[nb][mb][r];
+      }
+    if (has_next) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[m][n], 4 consecutive n per lane and register quad ----
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb) {
+    const int m = m0 + 64 * wm + 32 * mb + lq;
+    if (m >= m_end) continue;
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int n = n0 + 64 * wn + 32 * nb + 8 * r4 + 4 * lh;
+        if (n >= N) continue;
+        uint32_t w[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const uint32_t lo = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e], p.out_dtype);
+          const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
+          w[e] = lo | (hi << 16);
+        }
+        uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
+        if (n + 4 <= N) {
+          *(u32x2*)dst = u32x2{w[0], w[1]};
+        } else {
+          for (int e = 0; e < N - n; ++e) dst[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+        }
+      }
+    }
+  }
+}
+
+static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
+  const int grid = p.num_m_tiles_bound * p.n_tiles;
+  if (grid <= 0) return hipSuccess;
+  // MFMA A operand = GEMM matrix B, MFMA B operand = GEMM matrix A
+  const int sel = (p.b_is_e5m2 ? 2 : 0) | (p.a_is_e5m2 ? 1 : 0);
+  switch (sel) {
+    case 0: group_gemm_fp8_kernel<false, false><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
+    case 1: group_gemm_fp8_kernel<false, true><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
+    case 2: group_gemm_fp8_kernel<true, false><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
+    default: group_gemm_fp8_kernel<true, true><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
+  }
+  return hipGetLastError();
+}
+
+static int fill_and_check(GemmParams& p, const char* who, const void* a, const void* b, const void* sa,
+                          const void* sb, void* d, int m_total, int n, int k, int gm, int gn, int gk,
+                          int scale_k_major, int a_dt, int b_dt, int d_dt) {
+  FI_REQUIRE(a && b && sa && sb && d, "%s: null tensor", who);
+  FI_REQUIRE((a_dt == FI_DTYPE_FP8_E4M3 || a_dt == FI_DTYPE_FP8_E5M2) &&
+                 (b_dt == FI_DTYPE_FP8_E4M3 || b_dt == FI_DTYPE_FP8_E5M2),
+             "%s: a and b must be fp8 (e4m3 / e5m2)", who);
+  FI_REQUIRE(d_dt == FI_DTYPE_F16 || d_dt == FI_DTYPE_BF16, "%s: output dtype must be f16/bf16", who);
+  FI_REQUIRE((gm == 1 || gm == 128) && gn == 128 && gk == 128,
+             "%s: scale granularity (%d,%d,%d) unsupported; (1,128,128) or (128,128,128)", who, gm, gn, gk);
+  FI_REQUIRE(n % 8 == 0 && k % 16 == 0, "%s: n must be a multiple of 8 and k of 16", who);
+  FI_REQUIRE(k % 128 == 0, "%s: k must be a multiple of the 128-wide scale block", who);
+  FI_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)d % 8) == 0,
+             "%s: a/b must be 16-byte aligned", who);
+  memset(&p, 0, sizeof(p));
+  p.a = (const uint8_t*)a;
+  p.b = (const uint8_t*)b;
+  p.a_scale = (const float*)sa;
+  p.b_scale = (const float*)sb;
+  p.d = d;
+  p.m_total = m_total;
+  p.n = n;
+  p.k = k;
+  p.a_gran_m = gm;
+  p.scale_k_major = scale_k_major;
+  p.out_dtype = d_dt;
+  p.n_tiles = ceil_div(n, kBN);
+  p.a_is_e5m2 = a_dt == FI_DTYPE_FP8_E5M2;
+  p.b_is_e5m2 = b_dt == FI_DTYPE_FP8_E5M2;
+  return 0;
+}
+
+}  // namespace fi
+
+using namespace fi;
+
+extern "C" FI_API int fi_gemm_fp8_nt_groupwise(const void* a, const void* b, const void* a_scale,
+                                               const void* b_scale, void* d, int32_t m, int32_t n,
+                                               int32_t k, int32_t gran_m, int32_t gran_n,
+                                               int32_t gran_k, int32_t scale_k_major, int32_t a_dtype,
+                                               int32_t b_dtype, int32_t d_dtype, fi_stream_t stream) {
+  if (m == 0 || n == 0) return 0;
+  GemmParams p;
+  if (fill_and_check(p, "gemm_fp8_nt_groupwise", a, b, a_scale, b_scale, d, m, n, k, gran_m, gran_n,
+                     gran_k, scale_k_major, a_dtype, b_dtype, d_dtype))
+    return 1;
+  p.num_groups = 1;
+  p.m_indptr = nullptr;
+  p.num_m_tiles_bound = ceil_div(m, kBM);
+  FI_HIP_CALL(launch_gemm(p, (hipStream_t)stream));
+  return 0;
+}
+
+extern "C" FI_API int fi_group_gemm_fp8_nt_groupwise(const void* a, const void* b, const void* a_scale,
+                                                     const void* b_scale, void* d,
+                                                     const int32_t* m_indptr, int32_t num_groups,
+                                                     int32_t cum_m, int32_t n, int32_t k,
+                                                     int32_t gran_m, int32_t gran_n, int32_t gran_k,
+                                                     int32_t scale_k_major, int32_t a_dtype,
+                                                     int32_t b_dtype, int32_t d_dtype,
+                                                     fi_stream_t stream) {
+  if (cum_m == 0 || n == 0 || num_groups == 0) return 0;
+  GemmParams p;
+  if (fill_and_check(p, "group_gemm_fp8_nt_groupwise", a, b, a_scale, b_scale, d, cum_m, n, k, gran_m,
+                     gran_n, gran_k, scale_k_major, a_dtype, b_dtype, d_dtype))
+    return 1;
+  FI_REQUIRE(m_indptr, "group_gemm_fp8_nt_groupwise: null m_indptr");
+  p.num_groups = num_groups;
+  p.m_indptr = m_indptr;
+  // every group adds at most one partial tile on top of cum_m / 128
+  p.num_m_tiles_bound = cum_m / kBM + num_groups;
+  FI_HIP_CALL(launch_gemm(p, (hipStream_t)stream));
+  return 0;
+}

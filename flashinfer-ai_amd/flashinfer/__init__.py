@@ -15,6 +15,8 @@ from .decode import (
     CUDAGraphBatchDecodeWithPagedKVCacheWrapper as CUDAGraphBatchDecodeWithPagedKVCacheWrapper,
 )
 from .decode import single_decode_with_kv_cache as single_decode_with_kv_cache
+from .gemm import gemm_fp8_nt_groupwise as gemm_fp8_nt_groupwise
+from .gemm import group_gemm_fp8_nt_groupwise as group_gemm_fp8_nt_groupwise
 from .page import get_seq_lens as get_seq_lens
 from .prefill import (
     BatchPrefillWithPagedKVCacheWrapper as BatchPrefillWithPagedKVCacheWrapper,

@@ -179,6 +179,8 @@ EXPORTED_SYMBOLS = [
     "fi_batch_prefill_plan",
     "fi_batch_prefill_paged_run",
     "fi_single_prefill_run",
+    "fi_gemm_fp8_nt_groupwise",
+    "fi_group_gemm_fp8_nt_groupwise",
 ]
 
 
@@ -207,6 +209,8 @@ def lib() -> C.CDLL:
     l.fi_batch_prefill_plan.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp] + [i32] * 12 + [i64p, vp]
     l.fi_batch_prefill_paged_run.argtypes = [vp, sz, vp, sz, i64p, i32, C.POINTER(BatchPrefillParams), vp]
     l.fi_single_prefill_run.argtypes = [C.POINTER(SinglePrefillParams), vp, sz, vp]
+    l.fi_gemm_fp8_nt_groupwise.argtypes = [vp] * 5 + [i32] * 10 + [vp]
+    l.fi_group_gemm_fp8_nt_groupwise.argtypes = [vp] * 6 + [i32] * 11 + [vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(l, name)
         if name not in ("fi_last_error",):

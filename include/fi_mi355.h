@@ -272,6 +272,27 @@ typedef struct fi_single_prefill_params {
 FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* params, void* tmp, size_t tmp_bytes,
                           fi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * fp8 groupwise-scaled GEMM / grouped GEMM ("nt": D = A . B^T, B given as (n, k)).
+ * ref: gemm_fp8_nt_groupwise csrc/gemm_sm100_binding.cu:23, csrc/gemm_groupwise_sm100.cu:89-120;
+ * group_gemm_fp8_nt_groupwise csrc/group_gemm_sm100_binding.cu:34,
+ * csrc/group_gemm_fp8_groupwise_sm100.cu:89-124; Python flashinfer/gemm.py:2321-2484, 2657-2811.
+ *   a: (m | cum_m, k) fp8;  b: (n, k) | (G, n, k) fp8;  d: (m | cum_m, n) f16/bf16
+ *   scale_k_major = 0 ("MN"): a_scale (k/128, m/gran_m), b_scale ([G,] k/128, n/128)
+ *   scale_k_major = 1 ("K") : a_scale (m/gran_m, k/128), b_scale ([G,] n/128, k/128)
+ *   m_indptr: int32 [G+1] on the DEVICE (ref: gemm.py:2689-2691; entries multiples of 4).
+ * The reference's workspace and mma_sm arguments have no counterpart (no workspace is needed).
+ * ---------------------------------------------------------------------------------------------- */
+FI_API int fi_gemm_fp8_nt_groupwise(const void* a, const void* b, const void* a_scale, const void* b_scale,
+                             void* d, int32_t m, int32_t n, int32_t k, int32_t gran_m, int32_t gran_n,
+                             int32_t gran_k, int32_t scale_k_major, int32_t a_dtype, int32_t b_dtype,
+                             int32_t d_dtype, fi_stream_t stream);
+FI_API int fi_group_gemm_fp8_nt_groupwise(const void* a, const void* b, const void* a_scale,
+                                   const void* b_scale, void* d, const int32_t* m_indptr,
+                                   int32_t num_groups, int32_t cum_m, int32_t n, int32_t k,
+                                   int32_t gran_m, int32_t gran_n, int32_t gran_k, int32_t scale_k_major,
+                                   int32_t a_dtype, int32_t b_dtype, int32_t d_dtype, fi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,92 @@
+"""GPU parity: fp8 groupwise (grouped) GEMM against dequantise-then-matmul, the reference's own check
+(tests/GEMM/test_groupwise_scaled_gemm_fp8.py:35-71, 135-192; atol = rtol = 1e-2 in bf16 output)."""
+import math
+
+import pytest
+import torch
+
+from oracle import gemm_ref as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("m", [4, 128, 300, 1024])
+@pytest.mark.parametrize("n,k", [(128, 128), (256, 512), (1032, 256)])
+@pytest.mark.parametrize("mode", ["MN", "K"])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+def test_gemm_fp8_nt_groupwise(m, n, k, mode, out_dtype):
+    import flashinfer
+
+    torch.manual_seed(0)
+    a = torch.randn(m, k)
+    b = torch.randn(n, k) / math.sqrt(k)
+    n_pad = -(-n // 128) * 128
+    b_pad = torch.zeros(n_pad, k)
+    b_pad[:n] = b
+    a8, sa = G.quantize_fp8(a, (1, 128), mode)
+    b8p, sb = G.quantize_fp8(b_pad, (128, 128), mode)
+    b8 = b8p[:n].contiguous()
+    out = flashinfer.gemm_fp8_nt_groupwise(a8.to(DEV), b8.to(DEV), sa.to(DEV), sb.to(DEV), scale_major_mode=mode,
+                                           out_dtype=out_dtype)
+    ref = G.gemm_fp8_nt_groupwise_ref(a8, b8p, sa, sb, mode)[:, :n]
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("ms", [[4, 128, 0, 260], [512, 512], [128] * 8, [4]])
+@pytest.mark.parametrize("n,k", [(256, 256), (512, 1024)])
+@pytest.mark.parametrize("mode", ["MN", "K"])
+def test_group_gemm_fp8_nt_groupwise(ms, n, k, mode):
+    import flashinfer
+
+    torch.manual_seed(0)
+    g = len(ms)
+    cum = sum(ms)
+    a = torch.randn(cum, k)
+    b = torch.randn(g, n, k) / math.sqrt(k)
+    a8, sa = G.quantize_fp8(a, (1, 128), mode)
+    b8, sb = G.quantize_fp8(b, (1, 128, 128), mode)
+    m_indptr = torch.tensor([0] + list(torch.tensor(ms).cumsum(0)), dtype=torch.int32)
+    out = flashinfer.group_gemm_fp8_nt_groupwise(a8.to(DEV), b8.to(DEV), sa.to(DEV), sb.to(DEV), m_indptr.to(DEV),
+                                                 scale_major_mode=mode)
+    ref = G.group_gemm_fp8_nt_groupwise_ref(a8, b8, sa, sb, m_indptr, mode)
+    assert out.dtype == torch.bfloat16
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
+def test_group_gemm_exact_small_integers():
+    """Known-answer: small-integer operands and power-of-two scales are exact in fp8 x fp8 -> f32, so the
+    kernel must reproduce the integer result bit for bit (catches operand-layout / k-order mistakes that a
+    random-data tolerance could hide)."""
+    import flashinfer
+
+    torch.manual_seed(1)
+    g, m, n, k = 2, 132, 136, 256
+    a = torch.randint(-4, 5, (g * m, k)).float()
+    b = torch.randint(-4, 5, (g, n, k)).float()
+    a8, b8 = a.to(torch.float8_e4m3fn), b.to(torch.float8_e4m3fn)
+    sa = torch.pow(2.0, torch.randint(-2, 3, (k // 128, g * m)).float())
+    sb = torch.pow(2.0, torch.randint(-2, 3, (g, k // 128, -(-n // 128))).float())
+    m_indptr = torch.tensor([0, m, 2 * m], dtype=torch.int32)
+    out = flashinfer.group_gemm_fp8_nt_groupwise(a8.to(DEV), b8.to(DEV), sa.to(DEV), sb.to(DEV), m_indptr.to(DEV),
+                                                 out_dtype=torch.float16)
+    ref = torch.zeros(g * m, n, dtype=torch.float64)
+    for gi in range(g):
+        for kb in range(k // 128):
+            part = a[gi * m:(gi + 1) * m, kb * 128:(kb + 1) * 128].double() @ b[gi, :, kb * 128:(kb + 1) * 128].double().T
+            ref[gi * m:(gi + 1) * m] += part * sa[kb, gi * m:(gi + 1) * m, None].double() * \
+                sb[gi, kb].double().repeat_interleave(128)[:n][None]
+    assert ref.abs().max() < 60000
+    torch.testing.assert_close(out.float().cpu(), ref.float().half().float(), atol=0, rtol=0)
+
+
+def test_gemm_errors():
+    import flashinfer
+
+    a = torch.zeros(8, 128, device=DEV).to(torch.float8_e4m3fn)
+    b = torch.zeros(16, 256, device=DEV).to(torch.float8_e4m3fn)
+    s = torch.ones(1, 8, device=DEV)
+    with pytest.raises(ValueError):
+        flashinfer.gemm_fp8_nt_groupwise(a, b, s, s, scale_major_mode="MN")
+    with pytest.raises(ValueError):
+        flashinfer.gemm_fp8_nt_groupwise(a, a, s, s, scale_major_mode="MN", out_dtype=torch.float32)
