@@ -5,6 +5,15 @@ v0.3.1 (ref: flashinfer/__init__.py:23-145), backed by hand-written HIP kernels 
 ``libfi_mi355.so`` (include/fi_mi355.h).  Only the path named in DESIGN.md is provided.
 """
 from . import _lib as _lib
+from .cascade import (
+    BatchDecodeWithSharedPrefixPagedKVCacheWrapper as BatchDecodeWithSharedPrefixPagedKVCacheWrapper,
+)
+from .cascade import (
+    BatchPrefillWithSharedPrefixPagedKVCacheWrapper as BatchPrefillWithSharedPrefixPagedKVCacheWrapper,
+)
+from .cascade import (
+    MultiLevelCascadeAttentionWrapper as MultiLevelCascadeAttentionWrapper,
+)
 from .cascade import merge_state as merge_state
 from .cascade import merge_state_in_place as merge_state_in_place
 from .cascade import merge_states as merge_states
@@ -17,6 +26,8 @@ from .decode import (
 from .decode import single_decode_with_kv_cache as single_decode_with_kv_cache
 from .gemm import gemm_fp8_nt_groupwise as gemm_fp8_nt_groupwise
 from .gemm import group_gemm_fp8_nt_groupwise as group_gemm_fp8_nt_groupwise
+from .page import append_paged_kv_cache as append_paged_kv_cache
+from .page import get_batch_indices_positions as get_batch_indices_positions
 from .page import get_seq_lens as get_seq_lens
 from .prefill import (
     BatchPrefillWithPagedKVCacheWrapper as BatchPrefillWithPagedKVCacheWrapper,

@@ -181,6 +181,8 @@ EXPORTED_SYMBOLS = [
     "fi_single_prefill_run",
     "fi_gemm_fp8_nt_groupwise",
     "fi_group_gemm_fp8_nt_groupwise",
+    "fi_get_batch_indices_positions",
+    "fi_append_paged_kv_cache",
 ]
 
 
@@ -211,6 +213,8 @@ def lib() -> C.CDLL:
     l.fi_single_prefill_run.argtypes = [C.POINTER(SinglePrefillParams), vp, sz, vp]
     l.fi_gemm_fp8_nt_groupwise.argtypes = [vp] * 5 + [i32] * 10 + [vp]
     l.fi_group_gemm_fp8_nt_groupwise.argtypes = [vp] * 6 + [i32] * 11 + [vp]
+    l.fi_get_batch_indices_positions.argtypes = [vp, vp, i32, i32, vp, vp, vp]
+    l.fi_append_paged_kv_cache.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp, i32, C.POINTER(PagedKV), vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(l, name)
         if name not in ("fi_last_error",):

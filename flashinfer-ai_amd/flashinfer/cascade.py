@@ -120,3 +120,200 @@ def merge_states(v: torch.Tensor, s: torch.Tensor) -> Tuple[torch.Tensor, torch.
             "merge_states",
         )
     return v_merged, s_merged
+
+
+# --------------------------------------------------------------------------------------------------
+# cascade wrappers (host orchestration only; ref: flashinfer/cascade.py:228-795)
+# --------------------------------------------------------------------------------------------------
+from typing import List, Union  # noqa: E402
+
+from .decode import BatchDecodeWithPagedKVCacheWrapper  # noqa: E402
+from .prefill import BatchPrefillWithPagedKVCacheWrapper, single_prefill_with_kv_cache  # noqa: E402
+
+
+class MultiLevelCascadeAttentionWrapper:
+    r"""Multi-level cascade attention over one unified page table: level ``i`` is a
+    :class:`BatchPrefillWithPagedKVCacheWrapper` whose "requests" are the KV segments shared at that
+    level; per-level partial states are folded with :func:`merge_state_in_place`.
+
+    >>> wrapper = flashinfer.MultiLevelCascadeAttentionWrapper(2, workspace_buffer, "NHD")
+    >>> wrapper.plan([shared_qo_indptr, unique_qo_indptr], [shared_kv_indptr, unique_kv_indptr],
+    ...              [shared_kv_indices, unique_kv_indices], [shared_last_page_len, unique_last_page_len],
+    ...              num_qo_heads, num_kv_heads, head_dim, page_size)
+    >>> o = wrapper.run(q, kv_cache)
+
+    (ref: flashinfer/cascade.py:228-555; layout docs/tutorials/kv_layout.rst:182-201)
+    """
+
+    def __init__(
+        self,
+        num_levels,
+        float_workspace_buffer: torch.Tensor,
+        kv_layout: str = "NHD",
+        use_cuda_graph: bool = False,
+        qo_indptr_buf_arr: Optional[List[torch.Tensor]] = None,
+        paged_kv_indptr_buf_arr: Optional[List[torch.Tensor]] = None,
+        paged_kv_indices_buf_arr: Optional[List[torch.Tensor]] = None,
+        paged_kv_last_page_len_buf_arr: Optional[List[torch.Tensor]] = None,
+    ) -> None:
+        self._use_cuda_graph = use_cuda_graph
+        if use_cuda_graph:
+            self._batch_prefill_wrappers = [
+                BatchPrefillWithPagedKVCacheWrapper(
+                    float_workspace_buffer, kv_layout, use_cuda_graph=True, qo_indptr_buf=qo_indptr_buf,
+                    paged_kv_indptr_buf=paged_kv_indptr_buf, paged_kv_indices_buf=paged_kv_indices_buf,
+                    paged_kv_last_page_len_buf=paged_kv_last_page_len_buf,
+                )
+                for (qo_indptr_buf, paged_kv_indptr_buf, paged_kv_indices_buf, paged_kv_last_page_len_buf)
+                in zip(qo_indptr_buf_arr, paged_kv_indptr_buf_arr, paged_kv_indices_buf_arr,
+                       paged_kv_last_page_len_buf_arr)
+            ]
+        else:
+            self._batch_prefill_wrappers = [
+                BatchPrefillWithPagedKVCacheWrapper(float_workspace_buffer, kv_layout)
+                for _ in range(num_levels)
+            ]
+        self._num_levels = num_levels
+        self._kv_layout = kv_layout
+
+    @property
+    def is_cuda_graph_enabled(self) -> bool:
+        return self._use_cuda_graph
+
+    def reset_workspace_buffer(
+        self, float_workspace_buffer: torch.Tensor, int_workspace_buffers: List[torch.Tensor]
+    ) -> None:
+        for wrapper, int_workspace_buffer in zip(self._batch_prefill_wrappers, int_workspace_buffers):
+            wrapper.reset_workspace_buffer(float_workspace_buffer, int_workspace_buffer)
+
+    def plan(
+        self,
+        qo_indptr_arr: List[torch.Tensor],
+        paged_kv_indptr_arr: List[torch.Tensor],
+        paged_kv_indices_arr: List[torch.Tensor],
+        paged_kv_last_page_len: List[torch.Tensor],
+        num_qo_heads: int,
+        num_kv_heads: int,
+        head_dim: int,
+        page_size: int,
+        causal: bool = False,
+        pos_encoding_mode: str = "NONE",
+        use_fp16_qk_reduction: bool = False,
+        sm_scale: Optional[float] = None,
+        window_left: int = -1,
+        logits_soft_cap: Optional[float] = None,
+        rope_scale: Optional[float] = None,
+        rope_theta: Optional[float] = None,
+        q_data_type: str = "float16",
+        kv_data_type: Optional[Union[str, torch.dtype]] = None,
+    ):
+        r"""Plan every level; the causal mask applies to the LAST level only (ref: cascade.py:505)."""
+        for i, (wrapper, qo_indptr, paged_kv_indptr, paged_kv_indices, last_page_len) in enumerate(
+            zip(self._batch_prefill_wrappers, qo_indptr_arr, paged_kv_indptr_arr, paged_kv_indices_arr,
+                paged_kv_last_page_len)
+        ):
+            wrapper.plan(
+                qo_indptr, paged_kv_indptr, paged_kv_indices, last_page_len, num_qo_heads, num_kv_heads,
+                head_dim, page_size, causal=causal if i == self._num_levels - 1 else False,
+                pos_encoding_mode=pos_encoding_mode, use_fp16_qk_reduction=use_fp16_qk_reduction,
+                sm_scale=sm_scale, window_left=window_left, logits_soft_cap=logits_soft_cap,
+                rope_scale=rope_scale, rope_theta=rope_theta, q_data_type=q_data_type,
+                kv_data_type=kv_data_type,
+            )
+
+    begin_forward = plan
+
+    def run(self, q: torch.Tensor, paged_kv_cache: torch.Tensor):
+        r"""q ``[batch_size, num_qo_heads, head_dim]`` against the unified paged cache."""
+        out, lse = self._batch_prefill_wrappers[-1].run(q, paged_kv_cache, return_lse=True)
+        for wrapper in self._batch_prefill_wrappers[:-1]:
+            out_i, lse_i = wrapper.run(q, paged_kv_cache, return_lse=True)
+            merge_state_in_place(out, lse, out_i, lse_i)
+        return out
+
+    forward = run
+
+
+class BatchDecodeWithSharedPrefixPagedKVCacheWrapper:
+    r"""Two-level decode: one dense shared prefix + per-request paged suffixes
+    (ref: flashinfer/cascade.py:558-795)."""
+
+    def __init__(self, float_workspace_buffer: torch.Tensor, kv_layout: str = "NHD") -> None:
+        self._batch_decode_wrapper = BatchDecodeWithPagedKVCacheWrapper(float_workspace_buffer, kv_layout)
+        self._kv_layout = kv_layout
+
+    def reset_workspace_buffer(self, float_workspace_buffer: torch.Tensor, int_workspace_buffer: torch.Tensor) -> None:
+        self._batch_decode_wrapper.reset_workspace_buffer(float_workspace_buffer, int_workspace_buffer)
+
+    def begin_forward(
+        self,
+        unique_kv_indptr: torch.Tensor,
+        unique_kv_indices: torch.Tensor,
+        unique_kv_last_page_len: torch.Tensor,
+        num_qo_heads: int,
+        num_kv_heads: int,
+        head_dim: int,
+        page_size: int,
+        data_type: str = "float16",
+    ) -> None:
+        dt = getattr(torch, data_type) if isinstance(data_type, str) else data_type
+        self._batch_decode_wrapper.plan(
+            unique_kv_indptr, unique_kv_indices, unique_kv_last_page_len, num_qo_heads, num_kv_heads,
+            head_dim, page_size, pos_encoding_mode="NONE", q_data_type=dt, kv_data_type=dt,
+        )
+
+    def forward(self, q: torch.Tensor, k_shared: torch.Tensor, v_shared: torch.Tensor,
+                unique_kv_cache: torch.Tensor) -> torch.Tensor:
+        r"""q ``[batch_size, num_qo_heads, head_dim]``; k_shared / v_shared the dense shared prefix."""
+        V_shared, S_shared = single_prefill_with_kv_cache(
+            q, k_shared, v_shared, causal=False, pos_encoding_mode="NONE", kv_layout=self._kv_layout,
+            sm_scale=self._batch_decode_wrapper._sm_scale, rope_scale=self._batch_decode_wrapper._rope_scale,
+            rope_theta=self._batch_decode_wrapper._rope_theta, return_lse=True,
+        )
+        V_unique, S_unique = self._batch_decode_wrapper.run(q, unique_kv_cache, return_lse=True)
+        merge_state_in_place(V_shared, S_shared, V_unique, S_unique)
+        return V_shared
+
+    def end_forward(self) -> None:
+        pass
+
+
+class BatchPrefillWithSharedPrefixPagedKVCacheWrapper:
+    r"""Two-level prefill/append: dense shared prefix + per-request paged suffixes
+    (ref: flashinfer/cascade.py:798-1075)."""
+
+    def __init__(self, float_workspace_buffer: torch.Tensor, kv_layout: str = "NHD") -> None:
+        self._batch_prefill_wrapper = BatchPrefillWithPagedKVCacheWrapper(float_workspace_buffer, kv_layout)
+        self._kv_layout = kv_layout
+
+    def reset_workspace_buffer(self, float_workspace_buffer: torch.Tensor, int_workspace_buffer: torch.Tensor) -> None:
+        self._batch_prefill_wrapper.reset_workspace_buffer(float_workspace_buffer, int_workspace_buffer)
+
+    def begin_forward(self, qo_indptr, paged_kv_indptr, paged_kv_indices, paged_kv_last_page_len,
+                      num_qo_heads: int, num_kv_heads: int, head_dim: int, page_size: int) -> None:
+        self._plan_args = (qo_indptr, paged_kv_indptr, paged_kv_indices, paged_kv_last_page_len,
+                           num_qo_heads, num_kv_heads, head_dim, page_size)
+        self._planned_key = None
+
+    def forward(self, q, k_shared, v_shared, unique_kv_cache, causal: bool = False,
+                use_fp16_qk_reduction: bool = False, sm_scale: Optional[float] = None,
+                rope_scale: Optional[float] = None, rope_theta: Optional[float] = None) -> torch.Tensor:
+        from .utils import _unpack_paged_kv_cache
+
+        k_cache, _ = _unpack_paged_kv_cache(unique_kv_cache, self._kv_layout)
+        key = (causal, sm_scale, q.dtype, k_cache.dtype)
+        if self._planned_key != key:  # the reference re-plans lazily with the forward-time options too
+            self._batch_prefill_wrapper.plan(*self._plan_args, causal=causal, sm_scale=sm_scale,
+                                             rope_scale=rope_scale, rope_theta=rope_theta,
+                                             q_data_type=q.dtype, kv_data_type=k_cache.dtype)
+            self._planned_key = key
+        V_shared, S_shared = single_prefill_with_kv_cache(
+            q, k_shared, v_shared, causal=False, pos_encoding_mode="NONE", kv_layout=self._kv_layout,
+            sm_scale=sm_scale, rope_scale=rope_scale, rope_theta=rope_theta, return_lse=True,
+        )
+        V_unique, S_unique = self._batch_prefill_wrapper.run(q, unique_kv_cache, return_lse=True)
+        merge_state_in_place(V_shared, S_shared, V_unique, S_unique)
+        return V_shared
+
+    def end_forward(self) -> None:
+        pass

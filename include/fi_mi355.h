@@ -293,6 +293,22 @@ FI_API int fi_group_gemm_fp8_nt_groupwise(const void* a, const void* b, const vo
                                    int32_t gran_m, int32_t gran_n, int32_t gran_k, int32_t scale_k_major,
                                    int32_t a_dtype, int32_t b_dtype, int32_t d_dtype, fi_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Page-table operations.  ref: append_paged_kv_cache csrc/flashinfer_page_binding.cu:36, csrc/page.cu,
+ * include/flashinfer/page.cuh:258-284, 345-411; get_batch_indices_positions flashinfer/page.py:169-221.
+ *   positions[i] = i + seq_lens[b] - append_indptr[b+1]   for append_indptr[b] <= i < append_indptr[b+1]
+ *   append: K/V row i (shape [nnz, num_kv_heads, head_dim], element strides given) is written at
+ *           page kv.indices[kv.indptr[b] + pos / page_size], entry pos % page_size.
+ * `kv->k_data` / `kv->v_data` are WRITTEN by fi_append_paged_kv_cache; kv->last_page_len is unused.
+ * ---------------------------------------------------------------------------------------------- */
+FI_API int fi_get_batch_indices_positions(const int32_t* append_indptr, const int32_t* seq_lens,
+                                   int32_t batch_size, int32_t nnz, int32_t* batch_indices,
+                                   int32_t* positions, fi_stream_t stream);
+FI_API int fi_append_paged_kv_cache(const void* append_key, const void* append_value, int64_t k_stride_n,
+                             int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
+                             const int32_t* batch_indices, const int32_t* positions, int32_t nnz,
+                             const fi_paged_kv_t* kv, fi_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
