@@ -97,8 +97,8 @@ def cpu_baseline(cfg, sample_requests=8, iters=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-permute", action="store_true", help="arange page table instead of a random permutation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -149,7 +149,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    per_step = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    kernel_ms = sum(per_step) / args.steps
 
     nbytes, flops = algorithmic_bytes_flops(cfg)
     if rank == 0:
@@ -192,6 +193,9 @@ def main():
                 "traffic": traffic,
                 "kernel": "fi::batch_decode_kernel (+ merge_n_kernel)",
                 "kernel_ms": kernel_ms,
+                "kernel_ms_median": sorted(per_step)[len(per_step) // 2],
+                "kernel_ms_min": min(per_step),
+                "kernel_ms_max": max(per_step),
                 "algorithmic_bytes_per_launch": nbytes,
             },
         }

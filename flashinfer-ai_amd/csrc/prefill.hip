@@ -171,6 +171,8 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
                  ((uintptr_t)kv.v_data % 16) == 0,
              "batch_prefill_paged_run: kv cache rows must be aligned to 8 elements");
 
+  FI_REQUIRE(kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31) && kv.stride_page >= 0 && kv.stride_n >= 0,
+             "batch_prefill_paged_run: kv page / token strides must be below 2^31 elements");
   PrefillKernelParams kp;
   memset(&kp, 0, sizeof(kp));
   kp.q = a->q;
@@ -239,6 +241,8 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
                  ((uintptr_t)a->k % 16) == 0 && ((uintptr_t)a->v % 16) == 0,
              "single_prefill_run: k/v rows must be aligned to 8 elements");
   const int vpage = 16;  // dense tensor == identity page table of 16-token pages
+  FI_REQUIRE(a->kv_stride_n >= 0 && (int64_t)vpage * a->kv_stride_n < (1ll << 31),
+             "single_prefill_run: kv token stride must be below 2^27 elements");
   PrefillKernelParams kp;
   memset(&kp, 0, sizeof(kp));
   kp.q = a->q;

@@ -8,9 +8,9 @@
 
 namespace fi {
 
-template <bool ROPE>
+template <bool ROPE, bool GENERAL>
 static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
-  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE>;
+  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE, GENERAL>;
   constexpr int smem = 2 * 2 * kTileKV * FI_PF_D * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -25,7 +25,9 @@ static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
 }
 
 hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t stream) {
-  return rope ? launch<true>(p, stream) : launch<false>(p, stream);
+  const bool general = p.use_alibi || p.logits_soft_cap > 0.f;
+  if (rope) return general ? launch<true, true>(p, stream) : launch<true, false>(p, stream);
+  return general ? launch<false, true>(p, stream) : launch<false, false>(p, stream);
 }
 
 }  // namespace fi

@@ -21,6 +21,8 @@
 //     fp16 / bf16 / fp8-KV / fp8-QKV; with fp8 Q the probabilities are rounded through e4m3 (x448) before
 //     P.V exactly as the reference does (hopper/variants.cuh:72, 84-90).
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace fi {
@@ -47,7 +49,7 @@ struct PrefillKernelParams {
   const float* scale_k;
   const float* scale_v;
   int64_t q_stride_n, q_stride_h;
-  int64_t kv_stride_page, kv_stride_n, kv_stride_h;
+  int64_t kv_stride_page, kv_stride_n, kv_stride_h;  // host checks stride_page / stride_n < 2^31
   int32_t num_work;
   int32_t num_qo_heads, num_kv_heads, group_size;
   int32_t page_size;
@@ -95,12 +97,23 @@ struct MfmaType<FI_DTYPE_BF16> {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((address_space(3))) void lds_void;
+
+// two f32 -> one dword of two 16-bit values (single v_cvt_pk_* instruction)
+template <int T16>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+  if constexpr (T16 == FI_DTYPE_BF16) {
+    using bf2 = __attribute__((ext_vector_type(2))) __bf16;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, bf2));
+  } else {
+    using h2 = __attribute__((ext_vector_type(2))) _Float16;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{a, b}, h2));
+  }
+}
 using s16x4 = __attribute__((ext_vector_type(4))) short;
 
 // 8 fp8 bytes -> 8 values of the 16-bit compute type, packed in a u32x4
 template <int T16, int FP8_DT>
 __device__ __forceinline__ u32x4 fp8x8_to_16(u32x2 raw) {
-  using M = MfmaType<T16>;
   u32x4 out;
 #pragma unroll
   for (int w = 0; w < 2; ++w) {
@@ -112,8 +125,8 @@ __device__ __forceinline__ u32x4 fp8x8_to_16(u32x2 raw) {
       lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw[w], false);
       hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)raw[w], true);
     }
-    out[2 * w] = (uint32_t)M::from_f32(lo[0]) | ((uint32_t)M::from_f32(lo[1]) << 16);
-    out[2 * w + 1] = (uint32_t)M::from_f32(hi[0]) | ((uint32_t)M::from_f32(hi[1]) << 16);
+    out[2 * w] = pack2<T16>(lo[0], lo[1]);
+    out[2 * w + 1] = pack2<T16>(hi[0], hi[1]);
   }
   return out;
 }
@@ -125,7 +138,8 @@ __device__ __forceinline__ float round_through_e4m3(float x) {
 }
 
 // T16: MFMA compute type; KVS: K/V storage dtype; QS: Q storage dtype; D: head_dim (64 / 128)
-template <int T16, int KVS, int QS, int D, bool ROPE>
+// GENERAL: ALiBi / logits soft cap compiled in (kept out of the common instantiation's hot loop)
+template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL>
 __global__ void __launch_bounds__(kPrefillThreads, 2)
     batch_prefill_kernel(const PrefillKernelParams p) {
   using M = MfmaType<T16>;
@@ -250,7 +264,8 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   if (p.scale_q) qk_scale *= p.scale_q[qo_head];
   if (p.scale_k) qk_scale *= p.scale_k[kv_head];
   const float c_log2 = qk_scale * kLog2e;
-  const bool plain_logits = !soft_cap && !p.use_alibi;
+  const float inv_qk_scale = 1.0f / qk_scale;
+  const float inv_cap = soft_cap ? 1.0f / p.logits_soft_cap : 0.f;
   const float slope = p.use_alibi ? p.alibi_slopes[qo_head] : 0.f;
 
   // ---- kv range of this workgroup ----
@@ -262,6 +277,10 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
   const int num_tiles = (kv_end + kTileKV - 1) / kTileKV;
+  // visible kv index range of this lane's query row (ref: prefill.cuh:782-786, variants.cuh:87-89);
+  // an empty range (vis_hi < vis_lo) can only arise from kv_len == 0, which runs no tile
+  const int vis_hi = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
+  const int vis_lo = p.window_left >= 0 ? max(q_pos - p.window_left, 0) : 0;
   // smallest query position of this WAVE (wave-uniform): tiles ending at or below it need no causal mask
   const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
   const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
@@ -271,28 +290,27 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   const int st_ch = tid % CPR;   // 16-byte chunk (8 elements) within the row
   const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
 
-  auto page_of = [&](int kvi) -> int {
-    const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
-    return p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
-  };
-  auto fetch_pages = [&](int tile, int (&pg)[NPASS]) {
+  const int64_t thread_off = head_off + st_ch * 8;  // element offset of this thread inside a kv row
+  const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
+  // page id and in-page entry of the rows this thread stages, fetched two tiles ahead
+  auto fetch_pages = [&](int tile, int (&pg)[NPASS], int (&en)[NPASS]) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      const int kvi = min(tile * kTileKV + ps * RPP + st_row, kv_len - 1);
-      pg[ps] = page_of(max(kvi, 0));
+      const int kvi = max(min(tile * kTileKV + ps * RPP + st_row, kv_len - 1), 0);
+      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+      en[ps] = kvi - pi * p.page_size;
+      pg[ps] = p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
     }
   };
   struct Stage {
     u32x4 k[NPASS], v[NPASS];
   };
-  auto issue_loads = [&](int tile, const int (&pg)[NPASS], Stage& st) {
+  auto issue_loads = [&](const int (&pg)[NPASS], const int (&en)[NPASS], Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      const int kvi = max(min(tile * kTileKV + ps * RPP + st_row, kv_len - 1), 0);
-      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
-      const int entry = kvi - pi * p.page_size;
-      const int64_t off = (int64_t)pg[ps] * p.kv_stride_page + head_off +
-                          (int64_t)entry * p.kv_stride_n + st_ch * 8;
+      // 32 x 32 -> 64-bit multiply-adds (strides fit in 31 bits, checked on the host)
+      const int64_t off = (int64_t)((uint64_t)(uint32_t)pg[ps] * stride_page32 +
+                                    (uint64_t)(uint32_t)en[ps] * stride_n32) + thread_off;
       if constexpr (KV_FP8) {
         const u32x2 rk = *(const u32x2*)((const uint8_t*)p.k + off);
         const u32x2 rv = *(const u32x2*)((const uint8_t*)p.v + off);
@@ -383,24 +401,26 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   float m_run = -1.0e30f, l_run = 0.f;
 
   if (num_tiles > 0) {
-    int pgA[NPASS], pgB[NPASS];
+    int pgA[NPASS], pgB[NPASS], enA[NPASS], enB[NPASS];
     Stage st;
-    fetch_pages(0, pgA);
-    issue_loads(0, pgA, st);
-    fetch_pages(1, pgB);
+    fetch_pages(0, pgA, enA);
+    issue_loads(pgA, enA, st);
+    fetch_pages(1, pgB, enB);
     write_stage(0, 0, st);
     __syncthreads();
-    for (int t = 0; t < num_tiles; ++t) {
-      const int buf = t & 1;
+    // The tile body is instantiated for the even and the odd LDS buffer so that every LDS address is a
+    // lane-constant register plus an immediate.
+    auto tile_body = [&](auto buf_c, const int t) {
+      constexpr int buf = decltype(buf_c)::value;
       const bool has_next = t + 1 < num_tiles;
       if (has_next) {
         // even/odd page-id registers alternate
-        if (buf == 0) {
-          issue_loads(t + 1, pgB, st);
-          fetch_pages(t + 2, pgA);
+        if constexpr (buf == 0) {
+          issue_loads(pgB, enB, st);
+          fetch_pages(t + 2, pgA, enA);
         } else {
-          issue_loads(t + 1, pgA, st);
-          fetch_pages(t + 2, pgB);
+          issue_loads(pgA, enA, st);
+          fetch_pages(t + 2, pgB, enB);
         }
       }
       const char* kb = lds_base + buf * 2 * TILE_BYTES;
@@ -421,50 +441,46 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
       }
 
       // ---- logits transform + mask (ref: variants.cuh:67-91, prefill.cuh:782-786) ----
+      // x holds c*logit (base-2 units) for the general path, or the RAW dot product on the plain path
+      // (scale folded into the exp2 argument: p = 2^(s*c - m)).
       const bool need_mask = (tile0 + kTileKV > kv_len) ||
                              (p.causal && tile0 + kTileKV - 1 > min_qpos_wave) ||
                              (p.window_left >= 0);
-      float x[2][16];
+      if constexpr (GENERAL) {
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float s = s_acc[kbk][r];
-          const int kv_idx = tile0 + 32 * kbk + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (plain_logits) {
-            s *= c_log2;
-          } else {
-            // ref: variants.cuh:67-76 -- alibi bias, then soft cap, then the base-2 scale
-            float lg = s * qk_scale;
-            if (p.use_alibi) lg += slope * (float)(kv_idx - qo_idx);
-            if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg / p.logits_soft_cap);
-            s = lg * kLog2e;
-          }
-          x[kbk][r] = s;
-        }
-      }
-      if (need_mask) {
-#pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
+        for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int kv_idx = tile0 + 32 * kbk + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            bool vis = kv_idx < kv_len;
-            if (p.causal) vis = vis && (kv_idx <= q_pos);
-            if (p.window_left >= 0) vis = vis && (kv_idx + p.window_left >= q_pos);
-            x[kbk][r] = vis ? x[kbk][r] : -INFINITY;
+            // ref: variants.cuh:67-76 -- alibi bias, then soft cap; kept in units of 1/c so that the
+            // common exp2(fma(x, c, -m)) below applies
+            float lg = s_acc[kbk][r] * qk_scale;
+            if (p.use_alibi) lg += slope * (float)(kv_idx - qo_idx);
+            if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg * inv_cap);
+            s_acc[kbk][r] = lg * inv_qk_scale;
           }
-        }
+      }
+      if (need_mask) {
+        // visible kv range of this lane's query: [vis_lo, vis_hi]; one unsigned compare per element
+        const unsigned span = (unsigned)(vis_hi - vis_lo);
+        const int base_idx = tile0 + 4 * lh - vis_lo;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned rel = (unsigned)(base_idx + 32 * kbk + (r & 3) + 8 * (r >> 2));
+            s_acc[kbk][r] = rel <= span ? s_acc[kbk][r] : -INFINITY;
+          }
       }
 
       // ---- online softmax (base 2; ref: prefill.cuh:861-953) ----
-      float mx = x[0][0];
+      float mx = s_acc[0][0];
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, x[kbk][r]);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kbk][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
+      const float m_new = fmaxf(m_run, mx * c_log2);  // c_log2 > 0
       const float alpha = fast_exp2(m_run - m_new);
       m_run = m_new;
       float psum = 0.f;
@@ -472,8 +488,8 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          x[kbk][r] = fast_exp2(x[kbk][r] - m_new);
-          psum += x[kbk][r];
+          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_new));
+          psum += s_acc[kbk][r];
         }
       l_run = l_run * alpha + psum;
       if (__any(alpha != 1.0f)) {
@@ -488,18 +504,20 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s2 = 0; s2 < 2; ++s2) {
           u32x4 w;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            float a = x[kbk][8 * s + 2 * j], b = x[kbk][8 * s + 2 * j + 1];
-            if (p.fp8_p_quant) {  // ref: hopper/variants.cuh:84-90 -- P * 448 rounded to e4m3
-              a = round_through_e4m3(a * 448.f);
-              b = round_through_e4m3(b * 448.f);
+            float a = s_acc[kbk][8 * s2 + 2 * j], b = s_acc[kbk][8 * s2 + 2 * j + 1];
+            if constexpr (Q_FP8) {  // ref: hopper/variants.cuh:84-90 -- P * 448 rounded to e4m3
+              const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a * 448.f, b * 448.f, 0, false);
+              const f32x2 back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+              a = back[0];
+              b = back[1];
             }
-            w[j] = (uint32_t)M::from_f32(a) | ((uint32_t)M::from_f32(b) << 16);
+            w[j] = pack2<T16>(a, b);
           }
-          pf[kbk][s] = __builtin_bit_cast(frag_t, w);
+          pf[kbk][s2] = __builtin_bit_cast(frag_t, w);
         }
 
       // ---- O^T += V^T P^T ----
@@ -523,14 +541,20 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
 
       if (has_next) write_stage(t + 1, buf ^ 1, st);
       __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < num_tiles; t += 2) {
+      tile_body(std::integral_constant<int, 0>{}, t);
+      tile_body(std::integral_constant<int, 1>{}, t + 1);
     }
+    if (t < num_tiles) tile_body(std::integral_constant<int, 0>{}, t);
   }
 
   // ---- finalize (ref: prefill.cuh:2378-2403; fp8: attention_updater.cuh:221-240) ----
   l_run += __shfl_xor(l_run, 32, 64);
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
-  if (p.fp8_p_quant) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
+  if constexpr (Q_FP8) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
   else if (p.scale_v) inv *= p.scale_v[kv_head];
   if (row_valid) {
     const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
@@ -539,15 +563,9 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int d0 = 32 * db + 8 * r4 + 4 * lh;
-        uint32_t w0, w1;
-        {
-          const uint32_t a = f32_to_16bit(o_acc[db][4 * r4 + 0] * inv, p.o_dtype);
-          const uint32_t b = f32_to_16bit(o_acc[db][4 * r4 + 1] * inv, p.o_dtype);
-          const uint32_t c = f32_to_16bit(o_acc[db][4 * r4 + 2] * inv, p.o_dtype);
-          const uint32_t d = f32_to_16bit(o_acc[db][4 * r4 + 3] * inv, p.o_dtype);
-          w0 = a | (b << 16);
-          w1 = c | (d << 16);
-        }
+        // the output type equals the compute type (checked on the host)
+        const uint32_t w0 = pack2<T16>(o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv);
+        const uint32_t w1 = pack2<T16>(o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv);
         *(u32x2*)((uint16_t*)p.o + ob + d0) = u32x2{w0, w1};
       }
     }

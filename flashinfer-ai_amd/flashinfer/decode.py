@@ -215,6 +215,8 @@ class BatchDecodeWithPagedKVCacheWrapper:
         self._use_cuda_graph = use_cuda_graph
         self._backend = backend
         self._plan_info: Optional[List[int]] = None
+        self._run_cache = None
+        self._plan_serial = 0
 
     @property
     def use_tensor_cores(self) -> bool:
@@ -228,6 +230,7 @@ class BatchDecodeWithPagedKVCacheWrapper:
         self, float_workspace_buffer: torch.Tensor, int_workspace_buffer: torch.Tensor
     ) -> None:
         r"""Swap the workspaces; a new pinned mirror of the int workspace is allocated."""
+        self._run_cache = None
         self._float_workspace_buffer = float_workspace_buffer
         self._int_workspace_buffer = int_workspace_buffer
         self._pin_memory_int_workspace_buffer = torch.empty(
@@ -352,6 +355,8 @@ class BatchDecodeWithPagedKVCacheWrapper:
             )
         self._plan_info = list(plan_info)
         self._plan_info_c = plan_info
+        self._plan_serial = getattr(self, "_plan_serial", 0) + 1
+        self._run_cache = None
         self._pos_encoding_mode = pos_encoding_mode
         self._window_left = window_left
         self._logits_soft_cap = logits_soft_cap
@@ -382,6 +387,7 @@ class BatchDecodeWithPagedKVCacheWrapper:
         self._sm_scale = sm_scale
         self._rope_scale = rope_scale
         self._rope_theta = rope_theta
+        self._run_cache = None
         return self.run(q, paged_kv_cache, q_scale=q_scale, k_scale=k_scale, v_scale=v_scale)
 
     def run(
@@ -415,6 +421,46 @@ class BatchDecodeWithPagedKVCacheWrapper:
             raise ValueError("attention sinks are not supported by this backend")
         if args:
             raise ValueError("additional kernel arguments require jit_args, which is not supported")
+        window_left = self._window_left if window_left is None else window_left
+        # window_left is part of the plan in the reference; keep the same contract
+        assert window_left == self._window_left
+        if return_lse and lse is None:
+            lse = torch.empty((q.size(0), q.size(1)), dtype=torch.float32, device=q.device)
+        if out is None:
+            out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+
+        # Steady-state calls (same tensors every layer / step) reuse the validated argument block.
+        cache_t = paged_kv_cache if torch.is_tensor(paged_kv_cache) else paged_kv_cache[0]
+        key = (q.data_ptr(), q.stride(), q.shape, cache_t.data_ptr(), cache_t.stride(), cache_t.shape,
+               None if torch.is_tensor(paged_kv_cache) else paged_kv_cache[1].data_ptr(),
+               out.data_ptr(), lse.data_ptr() if return_lse else 0, q_scale, k_scale, self._plan_serial)
+        cached = self._run_cache
+        if cached is not None and cached[0] == key:
+            params = cached[1]
+        else:
+            params = self._build_run_params(q, paged_kv_cache, q_scale, k_scale, out, lse if return_lse else None)
+            self._run_cache = (key, params, q, paged_kv_cache)  # keep the tensors alive with the pointers
+        dev_index = q.device.index
+        if torch.cuda.current_device() == dev_index:
+            status = self._lib_run(self._fws_ptr, self._fws_bytes, self._iws_ptr, self._iws_bytes,
+                                   self._plan_info_c, _lib.FI_DECODE_PLAN_INFO_LEN, params,
+                                   torch.cuda.current_stream().cuda_stream)
+        else:
+            with torch.cuda.device(q.device):
+                status = self._lib_run(self._fws_ptr, self._fws_bytes, self._iws_ptr, self._iws_bytes,
+                                       self._plan_info_c, _lib.FI_DECODE_PLAN_INFO_LEN, params,
+                                       torch.cuda.current_stream().cuda_stream)
+        if status != 0:
+            _lib.check(status, "BatchDecodeWithPagedKVCacheWrapper.run")
+        if v_scale is not None:
+            if is_float8(out):
+                out = (out.to(torch.float32) * v_scale).to(out.dtype)
+            else:
+                out *= v_scale
+        return (out, lse) if return_lse else out
+
+    def _build_run_params(self, q, paged_kv_cache, q_scale, k_scale, out, lse):
+        """Validate the run() arguments against the plan and build the C argument block."""
         _lib.require_gpu_tensor(q, "q")
         k_cache, v_cache = _unpack_paged_kv_cache(paged_kv_cache, self._kv_layout)
         _check_cached_qkv_data_type(q, k_cache, self._cached_q_data_type, self._cached_kv_data_type)
@@ -422,14 +468,11 @@ class BatchDecodeWithPagedKVCacheWrapper:
             k_cache, v_cache, self._kv_layout
         )
         pos_encoding_mode = self._pos_encoding_mode
-        window_left = self._window_left if window_left is None else window_left
-        # window_left is part of the plan in the reference; keep the same contract
-        assert window_left == self._window_left
+        _check_pos_encoding_mode(pos_encoding_mode)
         logits_soft_cap = self._logits_soft_cap
         sm_scale = self._sm_scale
         rope_scale = self._rope_scale
         rope_theta = self._rope_theta
-        _check_pos_encoding_mode(pos_encoding_mode)
         if logits_soft_cap is None:
             logits_soft_cap = 0.0
         if sm_scale is None:
@@ -451,22 +494,15 @@ class BatchDecodeWithPagedKVCacheWrapper:
         if num_kv_heads != self._num_kv_heads or page_size != self._page_size:
             raise ValueError("kv cache shape does not match the planned num_kv_heads / page_size")
         if q.stride(-1) != 1:
-            q = q.contiguous()
-        if return_lse:
-            if lse is None:
-                lse = torch.empty((q.size(0), q.size(1)), dtype=torch.float32, device=q.device)
-            else:
-                check_shape_dtype_device(lse, (q.size(0), q.size(1)), torch.float32, q.device, "lse")
-        if out is None:
-            out = torch.empty(q.shape, dtype=q.dtype, device=q.device)
-        else:
-            check_shape_dtype_device(out, q.shape, q.dtype, q.device, "out")
-            if not out.is_contiguous():
-                raise ValueError("out must be contiguous")
+            raise ValueError("q must be contiguous in head_dim")
+        if lse is not None:
+            check_shape_dtype_device(lse, (q.size(0), q.size(1)), torch.float32, q.device, "lse")
+        check_shape_dtype_device(out, q.shape, q.dtype, q.device, "out")
+        if not out.is_contiguous():
+            raise ValueError("out must be contiguous")
         alibi = None
         if pos_encoding_mode == "ALIBI":
             alibi = _get_cache_alibi_slopes_buf(q.shape[1], q.device)
-
         params = _lib.BatchDecodeParams(
             q=q.data_ptr(), q_stride_n=q.stride(0), q_stride_h=q.stride(1),
             kv=_lib.PagedKV(
@@ -478,32 +514,18 @@ class BatchDecodeWithPagedKVCacheWrapper:
                 page_size=page_size, num_kv_heads=num_kv_heads, head_dim=head_dim,
                 batch_size=self._batch_size, dtype=_lib.fi_dtype(k_cache.dtype),
             ),
-            o=out.data_ptr(), lse=_lib.ptr(lse) if return_lse else None,
+            o=out.data_ptr(), lse=_lib.ptr(lse),
             alibi_slopes=_lib.ptr(alibi), q_rope_offset=None, num_qo_heads=self._num_qo_heads,
             q_dtype=_lib.fi_dtype(q.dtype), pos_encoding_mode=PosEncodingMode[pos_encoding_mode].value,
-            window_left=window_left, logits_soft_cap=logits_soft_cap, sm_scale=sm_scale,
+            window_left=self._window_left, logits_soft_cap=logits_soft_cap, sm_scale=sm_scale,
             rope_rcp_scale=1.0 / rope_scale, rope_rcp_theta=1.0 / rope_theta,
         )
-        with torch.cuda.device(q.device):
-            _lib.check(
-                _lib.lib().fi_batch_decode_run(
-                    self._float_workspace_buffer.data_ptr(),
-                    self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size(),
-                    self._int_workspace_buffer.data_ptr(),
-                    self._int_workspace_buffer.numel(),
-                    self._plan_info_c,
-                    _lib.FI_DECODE_PLAN_INFO_LEN,
-                    C.byref(params),
-                    _lib.current_stream(q.device),
-                ),
-                "BatchDecodeWithPagedKVCacheWrapper.run",
-            )
-        if v_scale is not None:
-            if is_float8(out):
-                out = (out.to(torch.float32) * v_scale).to(out.dtype)
-            else:
-                out *= v_scale
-        return (out, lse) if return_lse else out
+        self._fws_ptr = self._float_workspace_buffer.data_ptr()
+        self._fws_bytes = self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size()
+        self._iws_ptr = self._int_workspace_buffer.data_ptr()
+        self._iws_bytes = self._int_workspace_buffer.numel()
+        self._lib_run = _lib.lib().fi_batch_decode_run
+        return C.byref(params)
 
     def forward_return_lse(
         self,
@@ -526,6 +548,7 @@ class BatchDecodeWithPagedKVCacheWrapper:
         self._sm_scale = sm_scale
         self._rope_scale = rope_scale
         self._rope_theta = rope_theta
+        self._run_cache = None
         return self.run(
             q, paged_kv_cache, q_scale=q_scale, k_scale=k_scale, v_scale=v_scale, return_lse=True
         )
