@@ -13,6 +13,7 @@
 // then sits on the lane, so the per-row A scale is one value per lane and the per-block B scale is wave
 // uniform; each K block's partial product is folded into the running f32 accumulator with one fma per
 // element (two-level accumulation, exactly the block-scaled definition).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -49,7 +50,11 @@ __device__ __forceinline__ f32x16g mfma_fp8(long a, long b, f32x16g c) {
 }
 
 // MA_E5M2 / MB_E5M2 refer to the MFMA A operand (= matrix B of the GEMM) and MFMA B operand (= matrix A)
-template <bool MA_E5M2, bool MB_E5M2>
+using i32x8g = __attribute__((ext_vector_type(8))) int;
+
+// MX: use the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit (E8M0 = 127) scales -- the plain fp8
+// product at twice the rate of the non-scaled fp8 MFMA (MI355X_MICROARCH.md, matrix cores).
+template <bool MA_E5M2, bool MB_E5M2, bool MX>
 __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[2][2][kBM * kBK];  // [stage][A|B]
   const int tid = threadIdx.x;
@@ -163,6 +168,30 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+    if constexpr (MX) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {  // 64 bytes of k per step: this lane holds bytes [64 kk + 32 lh, +32)
+        i32x8g fa[2], fb[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const u32x4 lo = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 4 * kk + 2 * lh)]);
+          const u32x4 hi = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 4 * kk + 2 * lh + 1)]);
+          fa[mb] = i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          const u32x4 lo = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 4 * kk + 2 * lh)]);
+          const u32x4 hi = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 4 * kk + 2 * lh + 1)]);
+          fb[nb] = i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            part[nb][mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                fb[nb], fa[mb], part[nb][mb], MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+    } else {
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) {  // 32 bytes of k per step pair: bytes [32 kp + 16 lh, +16)
       u32x4 fa[2], fb[2];
@@ -184,6 +213,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
           }
         }
       }
+    }
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -231,12 +261,22 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
   if (grid <= 0) return hipSuccess;
   // MFMA A operand = GEMM matrix B, MFMA B operand = GEMM matrix A
   const int sel = (p.b_is_e5m2 ? 2 : 0) | (p.a_is_e5m2 ? 1 : 0);
+  static const bool use_mx = [] {
+    const char* e = getenv("FI_GEMM_MX");
+    return e ? atoi(e) != 0 : true;
+  }();
+#define FI_GEMM_LAUNCH(A, B)                                                                   \
+  if (use_mx)                                                                                  \
+    group_gemm_fp8_kernel<A, B, true><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p);       \
+  else                                                                                         \
+    group_gemm_fp8_kernel<A, B, false><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p);
   switch (sel) {
-    case 0: group_gemm_fp8_kernel<false, false><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
-    case 1: group_gemm_fp8_kernel<false, true><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
-    case 2: group_gemm_fp8_kernel<true, false><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
-    default: group_gemm_fp8_kernel<true, true><<<dim3(grid), dim3(kGemmThreads), 0, stream>>>(p); break;
+    case 0: FI_GEMM_LAUNCH(false, false) break;
+    case 1: FI_GEMM_LAUNCH(false, true) break;
+    case 2: FI_GEMM_LAUNCH(true, false) break;
+    default: FI_GEMM_LAUNCH(true, true) break;
   }
+#undef FI_GEMM_LAUNCH
   return hipGetLastError();
 }
 
