@@ -302,23 +302,23 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
       pg[ps] = p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
     }
   };
+  // One register set stages K and then V of the next tile (K is written to LDS -- the OTHER buffer, free
+  // since the last barrier -- as soon as QK^T of the current tile has been issued, then the same registers
+  // take the V rows).
   struct Stage {
-    u32x4 k[NPASS], v[NPASS];
+    u32x4 r[NPASS];
   };
-  auto issue_loads = [&](const int (&pg)[NPASS], const int (&en)[NPASS], Stage& st) {
+  auto issue_loads = [&](const void* base, const int (&pg)[NPASS], const int (&en)[NPASS], Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       // 32 x 32 -> 64-bit multiply-adds (strides fit in 31 bits, checked on the host)
       const int64_t off = (int64_t)((uint64_t)(uint32_t)pg[ps] * stride_page32 +
                                     (uint64_t)(uint32_t)en[ps] * stride_n32) + thread_off;
       if constexpr (KV_FP8) {
-        const u32x2 rk = *(const u32x2*)((const uint8_t*)p.k + off);
-        const u32x2 rv = *(const u32x2*)((const uint8_t*)p.v + off);
-        st.k[ps] = u32x4{rk[0], rk[1], 0, 0};
-        st.v[ps] = u32x4{rv[0], rv[1], 0, 0};
+        const u32x2 rk = *(const u32x2*)((const uint8_t*)base + off);
+        st.r[ps] = u32x4{rk[0], rk[1], 0, 0};
       } else {
-        st.k[ps] = *(const u32x4*)((const uint16_t*)p.k + off);
-        st.v[ps] = *(const u32x4*)((const uint16_t*)p.v + off);
+        st.r[ps] = *(const u32x4*)((const uint16_t*)base + off);
       }
     }
   };
@@ -332,20 +332,14 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
     const int g64 = (ch >> 2) ^ f;
     return row * ROWB + (g64 << 6) + ((ch & 3) << 4);
   };
-  auto write_stage = [&](int tile, int buf, const Stage& st) {
+  auto write_k = [&](int tile, int buf, const Stage& st) {
     char* kb = lds_base + buf * 2 * TILE_BYTES;
-    char* vb = kb + TILE_BYTES;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + st_row;
-      u32x4 kw, vw;
-      if constexpr (KV_FP8) {
-        kw = fp8x8_to_16<T16, KVS>(u32x2{st.k[ps][0], st.k[ps][1]});
-        vw = fp8x8_to_16<T16, KVS>(u32x2{st.v[ps][0], st.v[ps][1]});
-      } else {
-        kw = st.k[ps];
-        vw = st.v[ps];
-      }
+      u32x4 kw;
+      if constexpr (KV_FP8) kw = fp8x8_to_16<T16, KVS>(u32x2{st.r[ps][0], st.r[ps][1]});
+      else kw = st.r[ps];
       if constexpr (ROPE) {
         // rotate K at its absolute position; the partner chunk sits CPR/2 lanes away
         const int kvi = tile * kTileKV + row;
@@ -370,6 +364,16 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
         kw = outw;
       }
       *(u32x4*)(kb + k_lds_off(row, st_ch)) = kw;
+    }
+  };
+  auto write_v = [&](int buf, const Stage& st) {
+    char* vb = lds_base + buf * 2 * TILE_BYTES + TILE_BYTES;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = ps * RPP + st_row;
+      u32x4 vw;
+      if constexpr (KV_FP8) vw = fp8x8_to_16<T16, KVS>(u32x2{st.r[ps][0], st.r[ps][1]});
+      else vw = st.r[ps];
       *(u32x4*)(vb + v_lds_off(row, st_ch)) = vw;
     }
   };
@@ -401,12 +405,16 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   float m_run = -1.0e30f, l_run = 0.f;
 
   if (num_tiles > 0) {
-    int pgA[NPASS], pgB[NPASS], enA[NPASS], enB[NPASS];
+    // pg/en: page ids + entries of the tile being staged (tile t+1 while t is consumed); pgn/enn: the
+    // ids of tile t+2, fetched as soon as the K/V loads of t+1 have been issued.
+    int pg[NPASS], en[NPASS], pgn[NPASS], enn[NPASS];
     Stage st;
-    fetch_pages(0, pgA, enA);
-    issue_loads(pgA, enA, st);
-    fetch_pages(1, pgB, enB);
-    write_stage(0, 0, st);
+    fetch_pages(0, pg, en);
+    issue_loads(p.k, pg, en, st);
+    write_k(0, 0, st);
+    issue_loads(p.v, pg, en, st);
+    fetch_pages(1, pgn, enn);
+    write_v(0, st);
     __syncthreads();
     // The tile body is instantiated for the even and the odd LDS buffer so that every LDS address is a
     // lane-constant register plus an immediate.
@@ -414,14 +422,12 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
       constexpr int buf = decltype(buf_c)::value;
       const bool has_next = t + 1 < num_tiles;
       if (has_next) {
-        // even/odd page-id registers alternate
-        if constexpr (buf == 0) {
-          issue_loads(pgB, enB, st);
-          fetch_pages(t + 2, pgA, enA);
-        } else {
-          issue_loads(pgA, enA, st);
-          fetch_pages(t + 2, pgB, enB);
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          pg[ps] = pgn[ps];
+          en[ps] = enn[ps];
         }
+        issue_loads(p.k, pg, en, st);
       }
       const char* kb = lds_base + buf * 2 * TILE_BYTES;
       const char* vb = kb + TILE_BYTES;
@@ -438,6 +444,12 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
           const u32x4 a = *(const u32x4*)(kb + kbk * 32 * ROWB + k_rd[ks]);
           s_acc[kbk] = M::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc[kbk]);
         }
+      }
+
+      if (has_next) {
+        write_k(t + 1, buf ^ 1, st);
+        issue_loads(p.v, pg, en, st);
+        fetch_pages(t + 2, pgn, enn);
       }
 
       // ---- logits transform + mask (ref: variants.cuh:67-91, prefill.cuh:782-786) ----
@@ -499,10 +511,11 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
           for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
       }
 
-      // ---- P^T fragments: accumulator registers 8s..8s+7 of block kb are k-step s ----
-      frag_t pf[2][2];
+      // ---- O^T += V^T P^T ----
+      // P^T fragments: accumulator registers 8s..8s+7 of block kb, rounded to 16 bit, are the B operand of
+      // k-step s (built right before use to keep registers free for LDS prefetch)
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
+      for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           u32x4 w;
@@ -517,29 +530,22 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
             }
             w[j] = pack2<T16>(a, b);
           }
-          pf[kbk][s2] = __builtin_bit_cast(frag_t, w);
-        }
-
-      // ---- O^T += V^T P^T ----
+          const frag_t pfrag = __builtin_bit_cast(frag_t, w);
 #pragma unroll
-      for (int db = 0; db < DBLK; ++db) {
-#pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-          for (int s = 0; s < 2; ++s) {
-            const char* base = vb + (32 * kbk + 16 * s) * ROWB + v_rd[db];
+          for (int db = 0; db < DBLK; ++db) {
+            const char* base = vb + (32 * kbk + 16 * s2) * ROWB + v_rd[db];
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4*)(base));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4*)(base + 8 * ROWB));
             using s16x8 = __attribute__((ext_vector_type(8))) short;
             const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pf[kbk][s], o_acc[db]);
+            o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pfrag, o_acc[db]);
           }
         }
       }
 
-      if (has_next) write_stage(t + 1, buf ^ 1, st);
+      if (has_next) write_v(buf ^ 1, st);
       __syncthreads();
     };
     int t = 0;
