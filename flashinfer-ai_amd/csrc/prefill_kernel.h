@@ -98,6 +98,15 @@ struct MfmaType<FI_DTYPE_BF16> {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 
+// value held by the partner lane (lane ^ 32) via v_permlane32_swap (VALU; no LDS round trip)
+__device__ __forceinline__ float swap_halves(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  // r[0] = {x.lo, x.lo}, r[1] = {x.hi, x.hi} per 32-lane half: the partner's value is the other half's
+  const bool upper = (threadIdx.x & 32) != 0;
+  return __builtin_bit_cast(float, upper ? r[0] : r[1]);
+}
+
 // two f32 -> one dword of two 16-bit values (single v_cvt_pk_* instruction)
 template <int T16>
 __device__ __forceinline__ uint32_t pack2(float a, float b) {
@@ -491,7 +500,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kbk][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, swap_halves(mx));
       const float m_new = fmaxf(m_run, mx * c_log2);  // c_log2 > 0
       const float alpha = fast_exp2(m_run - m_new);
       m_run = m_new;
@@ -557,7 +566,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   }
 
   // ---- finalize (ref: prefill.cuh:2378-2403; fp8: attention_updater.cuh:221-240) ----
-  l_run += __shfl_xor(l_run, 32, 64);
+  l_run += swap_halves(l_run);
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
   if constexpr (Q_FP8) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
