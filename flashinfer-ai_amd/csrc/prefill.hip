@@ -23,6 +23,21 @@ FI_PF_DECL_D(0, 2, 2) FI_PF_DECL_D(1, 2, 2)
 #undef FI_PF_DECL
 #undef FI_PF_DECL_D
 
+hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, hipStream_t stream);
+
+// fp8-native kernel (MX-scaled MFMA for both contractions): e4m3 q/k/v, head_dim 128, pages of a multiple
+// of 4 tokens, plain logits, no fused RoPE, no sliding window.  FI_PREFILL_FP8_NATIVE=0 forces the
+// upcast-to-16-bit kernel (same arithmetic, kept as the cross-check).
+static bool use_fp8_native(const PrefillKernelParams& kp, int q_dt, int kv_dt, int head_dim, int rope) {
+  static const bool enabled = [] {
+    const char* e = getenv("FI_PREFILL_FP8_NATIVE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return enabled && q_dt == FI_DTYPE_FP8_E4M3 && kv_dt == FI_DTYPE_FP8_E4M3 && head_dim == 128 &&
+         kp.page_size % 4 == 0 && !rope && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
+         kp.window_left < 0;
+}
+
 static prefill_launch_fn find_prefill(int t16, int kvs, int qs, int d) {
 #define FI_TRY(T, K, Q)                                       \
   if (t16 == T && kvs == K && qs == Q) {                      \
@@ -211,6 +226,10 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
+  if (use_fp8_native(kp, a->q_dtype, kv.dtype, kv.head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA)) {
+    FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, stream));
+    return 0;
+  }
   FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
   return 0;
 }
@@ -277,6 +296,10 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
+  if (use_fp8_native(kp, a->q_dtype, a->kv_dtype, a->head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA)) {
+    FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, stream));
+    return 0;
+  }
   FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
   return 0;
 }

@@ -1,0 +1,350 @@
+// fp8-native batch paged prefill for gfx950 (BASELINE config C3): Q, K, V are e4m3 and BOTH contractions
+// run on the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit (E8M0 = 127) block scales,
+// i.e. the plain fp8 product at twice the rate of the 16-bit / non-scaled fp8 MFMA.
+//
+// Same decomposition as prefill_kernel.h (workgroup = 4 waves = 128 GQA-packed query rows x one kv head,
+// 64-row kv tiles, S^T = K Q^T with the query row on the lane, O^T += V^T P^T with the S^T accumulator
+// registers as the B operand).  Differences:
+//   * K=64 per MFMA: S^T needs 2 MFMAs per 32-row kv block (head_dim 128), O^T needs ONE MFMA per 32-row
+//     block of head_dim per 64-row kv tile: 8 MFMAs (512 pipe cycles) per tile and wave instead of 32 (1024).
+//   * P is quantised to e4m3 (x448) in registers exactly as the reference does
+//     (hopper/variants.cuh:72, 84-90) and used directly as the B operand: lane (q, h) holds the 32
+//     probabilities kv = 32 kb + 8 g + 4 h + e  (kb<2, g<4, e<4) in accumulator order.
+//   * V has to be the A operand with that same k order along each head_dim row, so the V tile is stored
+//     TRANSPOSED in LDS: image [128 d][64 B] with byte (h*32 + kb*16 + 4 g + e) of row d = V[kv][d].  The
+//     transpose is done when the tile is staged: a thread loads 4 kv rows x 4 d bytes, transposes the 4x4
+//     byte block with v_perm_b32 and writes four dwords.
+//   * the fp8 K image is [64 kv][128 B]; both images are XOR-swizzled on 16-byte slots so that every
+//     ds_read_b128 is conflict-free.
+// Softmax arithmetic (ref hopper/attention_updater.cuh:167-256): row sum from the UNROUNDED probabilities,
+// O *= scale_v / 448 / rowsum at the end, lse = m + log2(sum) in base 2.
+#pragma once
+#include <type_traits>
+
+#include "prefill_kernel.h"
+
+namespace fi {
+
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+
+__device__ __forceinline__ f32x16 mfma_fp8_k64(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, /*A fmt e4m3*/ 0, /*B fmt e4m3*/ 0, 0,
+                                                         0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
+// OUT16: output dtype (FI_DTYPE_F16 / FI_DTYPE_BF16); head_dim 128; page_size % 4 == 0
+template <int OUT16>
+__global__ void __launch_bounds__(kPrefillThreads, 2)
+    batch_prefill_fp8_kernel(const PrefillKernelParams p) {
+  constexpr int D = 128;
+  constexpr int K_ROWB = 128;               // bytes per row of the K image (one kv row)
+  constexpr int V_ROWB = 64;                // bytes per row of the V^T image (one head_dim row)
+  constexpr int K_TILE = kTileKV * K_ROWB;  // 8 KB
+  constexpr int V_TILE = D * V_ROWB;        // 8 KB
+  constexpr int STAGE = K_TILE + V_TILE;
+  constexpr int DBLK = D / 32;
+
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 31;
+  const int lh = lane >> 5;
+
+  // ---- (request, q tile, kv head): same mapping as prefill_kernel.h ----
+  const int total = p.num_work * p.num_kv_heads;
+  int logical;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  const int kv_head = logical / p.num_work;
+  const int work = logical - kv_head * p.num_work;
+  int req = 0, q_tile = work;
+  if (p.request_indices) {
+    req = p.request_indices[work];
+    q_tile = p.qo_tile_indices[work];
+    if (req < 0) return;
+  }
+  int qo_start = 0, qo_len, kv_len, page_begin = 0;
+  if (p.qo_indptr) {
+    qo_start = p.qo_indptr[req];
+    qo_len = p.qo_indptr[req + 1] - qo_start;
+  } else {
+    qo_len = p.single_qo_len;
+  }
+  if (p.kv_indptr) {
+    page_begin = p.kv_indptr[req];
+    const int np = p.kv_indptr[req + 1] - page_begin;
+    kv_len = np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0;
+  } else {
+    kv_len = p.single_kv_len;
+  }
+  const int G = p.group_size;
+  const int packed_len = qo_len * G;
+  const int row0 = q_tile * kTileQ + wave * 32;
+  const int pr = row0 + lq;
+  const bool row_valid = pr < packed_len;
+  const int prc = row_valid ? pr : (packed_len > 0 ? packed_len - 1 : 0);
+  const int qo_idx = (int)fast_div((uint32_t)prc, p.group_div);
+  const int hg = prc - qo_idx * G;
+  const int qo_head = kv_head * G + hg;
+  const int q_pos = kv_len - qo_len + qo_idx;
+
+  // ---- Q fragments: lane (q, h) holds bytes [64 kk + 32 h, +32) of its row ----
+  i32x8 qf[2];
+  {
+    const uint8_t* qrow = (const uint8_t*)p.q + (int64_t)(qo_start + qo_idx) * p.q_stride_n +
+                          (int64_t)qo_head * p.q_stride_h;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const u32x4 lo = *(const u32x4*)(qrow + 64 * kk + 32 * lh);
+      const u32x4 hi = *(const u32x4*)(qrow + 64 * kk + 32 * lh + 16);
+      qf[kk] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    }
+  }
+
+  float qk_scale = p.sm_scale;
+  if (p.scale_q) qk_scale *= p.scale_q[qo_head];
+  if (p.scale_k) qk_scale *= p.scale_k[kv_head];
+  const float c_log2 = qk_scale * kLog2e;
+
+  int kv_end = kv_len;
+  if (p.causal) {
+    const int last_pr = min(q_tile * kTileQ + kTileQ, packed_len) - 1;
+    const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
+    kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
+  }
+  const int num_tiles = (kv_end + kTileKV - 1) / kTileKV;
+  const int vis_hi = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
+  const int vis_lo = 0;
+  const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
+  const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
+
+  // ---- staging geometry ----
+  // K: thread -> (row = tid/8 + 32 pass, 16-byte chunk tid%8), 2 passes
+  // V: thread -> (kv group kg = tid/32 + 8 pass (4 rows each), d group dg = tid%32 (4 bytes)), 2 passes
+  const int k_row = tid >> 3, k_ch = tid & 7;
+  const int v_kg = tid >> 5, v_dg = tid & 31;
+  const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
+  const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
+
+  // page ids: entries 0,1 = K passes, 2,3 = V passes (one page per 4-row group: page_size % 4 == 0)
+  auto fetch_pages = [&](int tile, int (&pg)[4], int (&en)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = i < 2 ? (k_row + 32 * i) : 4 * (v_kg + 8 * (i - 2));
+      const int kvi = max(min(tile * kTileKV + row, kv_len - 1), 0);
+      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+      en[i] = kvi - pi * p.page_size;
+      pg[i] = p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
+    }
+  };
+  struct Stage {
+    u32x4 k[2];
+    uint32_t v[2][4];
+  };
+  auto issue_loads = [&](int tile, const int (&pg)[4], const int (&en)[4], Stage& st) {
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int64_t off = (int64_t)((uint64_t)(uint32_t)pg[ps] * stride_page32 +
+                                    (uint64_t)(uint32_t)en[ps] * stride_n32) + head_off + k_ch * 16;
+      st.k[ps] = *(const u32x4*)((const uint8_t*)p.k + off);
+    }
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int64_t base = (int64_t)((uint64_t)(uint32_t)pg[2 + ps] * stride_page32 +
+                                     (uint64_t)(uint32_t)en[2 + ps] * stride_n32) + head_off + v_dg * 4;
+      // rows beyond kv_len are clamped to the last valid row (their probabilities are masked to 0)
+      const int row0v = tile * kTileKV + 4 * (v_kg + 8 * ps);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int di = min(row0v + i, kv_len - 1) - min(row0v, kv_len - 1);  // 0..3, clamped
+        st.v[ps][i] = *(const uint32_t*)((const uint8_t*)p.v + base + (int64_t)di * stride_n32);
+      }
+    }
+  };
+  auto k_lds_off = [](int row, int ch) { return row * K_ROWB + ((ch ^ ((row >> 1) & 7)) << 4); };
+  auto write_stage = [&](int buf, const Stage& st) {
+    char* kb = smem + buf * STAGE;
+    char* vb = kb + K_TILE;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) *(u32x4*)(kb + k_lds_off(k_row + 32 * ps, k_ch)) = st.k[ps];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const uint32_t r0 = st.v[ps][0], r1 = st.v[ps][1], r2 = st.v[ps][2], r3 = st.v[ps][3];
+      // 4x4 byte transpose: out[c] = (r0[c], r1[c], r2[c], r3[c])
+      const uint32_t t01l = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+      const uint32_t t01h = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+      const uint32_t t23l = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+      const uint32_t t23h = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+      uint32_t out[4];
+      out[0] = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);
+      out[1] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+      out[2] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+      out[3] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+      // kv0 = 4 kg = 32 kbk + 8 g + 4 h  ->  slot = 2 h + kbk, in-slot byte 4 g
+      const int kg = v_kg + 8 * ps;
+      const int kbk = kg >> 3, g = (kg >> 1) & 3, h = kg & 1;
+      const int slot = (2 * h + kbk) ^ (v_dg & 3);
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        *(uint32_t*)(vb + (4 * v_dg + c) * V_ROWB + (slot << 4) + 4 * g) = out[c];
+    }
+  };
+
+  // ---- per-lane LDS read offsets ----
+  int k_rd[2][2];  // [kk][half]: K row lq (+32 kb), 16-byte chunks 4 kk + 2 lh (+1)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) k_rd[kk][e] = k_lds_off(lq, 4 * kk + 2 * lh + e);
+  int v_rd[2];  // V^T row lq (+32 db): slots 2 lh (+1), swizzled by (d >> 2) & 3
+#pragma unroll
+  for (int e = 0; e < 2; ++e) v_rd[e] = lq * V_ROWB + (((2 * lh + e) ^ ((lq >> 2) & 3)) << 4);
+
+  f32x16 o_acc[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  if (num_tiles > 0) {
+    int pgA[4], enA[4], pgB[4], enB[4];
+    Stage st;
+    fetch_pages(0, pgA, enA);
+    issue_loads(0, pgA, enA, st);
+    fetch_pages(1, pgB, enB);
+    write_stage(0, st);
+    __syncthreads();
+    auto tile_body = [&](auto buf_c, const int t) {
+      constexpr int buf = decltype(buf_c)::value;
+      const bool has_next = t + 1 < num_tiles;
+      if (has_next) {
+        if constexpr (buf == 0) {
+          issue_loads(t + 1, pgB, enB, st);
+          fetch_pages(t + 2, pgA, enA);
+        } else {
+          issue_loads(t + 1, pgA, enA, st);
+          fetch_pages(t + 2, pgB, enB);
+        }
+      }
+      const char* kb = smem + buf * STAGE;
+      const char* vb = kb + K_TILE;
+      const int tile0 = t * kTileKV;
+
+      // ---- S^T = K Q^T: 2 kv blocks x 2 k-steps of 64 ----
+      f32x16 s_acc[2];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const u32x4 lo = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd[kk][0]);
+          const u32x4 hi = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd[kk][1]);
+          const i32x8 a = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+          s_acc[kbk] = mfma_fp8_k64(a, qf[kk], s_acc[kbk]);
+        }
+      }
+
+      const bool need_mask = (tile0 + kTileKV > kv_len) || (p.causal && tile0 + kTileKV - 1 > min_qpos_wave);
+      if (need_mask) {
+        const unsigned span = (unsigned)(vis_hi - vis_lo);
+        const int base_idx = tile0 + 4 * lh - vis_lo;
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned rel = (unsigned)(base_idx + 32 * kbk + (r & 3) + 8 * (r >> 2));
+            s_acc[kbk][r] = rel <= span ? s_acc[kbk][r] : -INFINITY;
+          }
+      }
+
+      // ---- online softmax (base 2) ----
+      float mx = s_acc[0][0];
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kbk][r]);
+      mx = fmaxf(mx, swap_halves(mx));
+      const float m_new = fmaxf(m_run, mx * c_log2);
+      const float alpha = fast_exp2(m_run - m_new);
+      m_run = m_new;
+      // p * 448 = 2^(s c - m + log2 448): the e4m3 scale is folded into the exponent; the row sum is taken
+      // from these unrounded values and divided by 448 once at the end
+      const float m_adj = m_new - 8.807354922057604f;  // log2(448)
+      float psum = 0.f;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_adj));
+          psum += s_acc[kbk][r];
+        }
+      l_run = l_run * alpha + psum;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+      }
+
+      // ---- P -> e4m3, the B operand (32 bytes per lane, accumulator order) ----
+      i32x8 p8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int kbk = j >> 2, r = 4 * (j & 3);
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(s_acc[kbk][r], s_acc[kbk][r + 1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(s_acc[kbk][r + 2], s_acc[kbk][r + 3], w, true);
+        p8[j] = w;
+      }
+
+      // ---- O^T += V^T P^T: one K=64 MFMA per 32 rows of head_dim ----
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+        const u32x4 lo = *(const u32x4*)(vb + db * 32 * V_ROWB + v_rd[0]);
+        const u32x4 hi = *(const u32x4*)(vb + db * 32 * V_ROWB + v_rd[1]);
+        const i32x8 a = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        o_acc[db] = mfma_fp8_k64(a, p8, o_acc[db]);
+      }
+
+      if (has_next) write_stage(buf ^ 1, st);
+      __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < num_tiles; t += 2) {
+      tile_body(std::integral_constant<int, 0>{}, t);
+      tile_body(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < num_tiles) tile_body(std::integral_constant<int, 0>{}, t);
+  }
+
+  // ---- finalize: l_run carries the x448 of P, so O / l_run is already free of it ----
+  l_run += swap_halves(l_run);
+  const bool empty = !(l_run > 0.f);
+  float inv = empty ? 0.f : 1.0f / l_run;
+  if (p.scale_v) inv *= p.scale_v[kv_head];
+  if (row_valid) {
+    const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = 32 * db + 8 * r4 + 4 * lh;
+        const uint32_t w0 = pack2<OUT16>(o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv);
+        const uint32_t w1 = pack2<OUT16>(o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv);
+        *(u32x2*)((uint16_t*)p.o + ob + d0) = u32x2{w0, w1};
+      }
+    }
+    if (p.lse && lh == 0)
+      p.lse[(int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head] =
+          empty ? FI_NEG_INF : m_run + fast_log2(l_run) - 8.807354922057604f;
+  }
+}
+
+}  // namespace fi

@@ -201,3 +201,34 @@ def test_prefill_cuda_graph_mode_and_errors():
         w.plan(qo_indptr.long(), indptr, indices, last, hq, hkv, d, ps)
     with pytest.raises(ValueError):
         w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, custom_mask=torch.ones(4, dtype=torch.bool))
+
+
+def test_fp8_native_kernel_matches_upcast_kernel():
+    """The fp8-native kernel (MX-scaled MFMA, transposed V image) and the upcast-to-bf16 kernel implement
+    the same arithmetic with the same 64-row tiles, so they must agree far tighter than the fp8 bar:
+    a sliding window wider than the sequence selects the upcast kernel without changing the result."""
+    import flashinfer
+
+    hq, hkv, d, ps = 16, 4, 128, 16
+    kv_lens, qo_lens = [700, 130], [300, 130]
+    torch.manual_seed(3)
+    cache16 = [torch.randn(-(-l // ps), 2, ps, hkv, d) for l in kv_lens]
+    cache = torch.cat(cache16).to(torch.float8_e4m3fn)
+    pages = [c.shape[0] for c in cache16]
+    indptr = torch.tensor([0] + list(torch.tensor(pages).cumsum(0)), dtype=torch.int32)
+    indices = torch.arange(sum(pages), dtype=torch.int32)
+    last = torch.tensor([(l - 1) % ps + 1 for l in kv_lens], dtype=torch.int32)
+    q8 = torch.randn(sum(qo_lens), hq, d).to(torch.float8_e4m3fn)
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    sq, sk, sv = torch.rand(hq) + 0.5, torch.rand(hkv) + 0.5, torch.rand(hkv) + 0.5
+    outs = []
+    for window in (-1, 1 << 30):
+        ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+        w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, "NHD")
+        w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps, causal=True,
+               window_left=window, q_data_type=torch.float8_e4m3fn, kv_data_type=torch.float8_e4m3fn,
+               o_data_type=torch.float16)
+        outs.append(w.run(q8.to(DEV), cache.to(DEV), return_lse=True, scale_q=sq.to(DEV), scale_k=sk.to(DEV),
+                          scale_v=sv.to(DEV)))
+    torch.testing.assert_close(outs[0][0].float(), outs[1][0].float(), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)
