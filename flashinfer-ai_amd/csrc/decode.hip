@@ -47,7 +47,7 @@ static decode_launch_fn find_launcher(int kv_dt, int head_dim) {
 }
 
 // q-head tile: the wave keeps GT query heads of one kv head in registers.
-static int pick_head_tile(int group_size) {
+static int pick_head_tile(int group_size, int kv_dt = FI_DTYPE_BF16) {
   static const int max_tile = [] {
     const char* e = getenv("FI_DECODE_MAX_HEAD_TILE");
     int v = e ? atoi(e) : 0;
@@ -57,6 +57,7 @@ static int pick_head_tile(int group_size) {
   // (they stream the same K/V rows, so HBM sees them once): measured 1.7-1.9x faster than an 8-head tile,
   // which is VALU-bound and spills (profiles/r01 notes in DESIGN.md).
   int t = group_size <= 1 ? 1 : group_size == 2 ? 2 : 4;
+  (void)kv_dt;
   return t < max_tile ? t : max_tile;
 }
 
@@ -126,7 +127,7 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
     FI_REQUIRE(indptr_h[i + 1] >= indptr_h[i], "batch_decode_plan: indptr must be non-decreasing");
 
   const int group = num_qo_heads / num_kv_heads;
-  const int gt = pick_head_tile(group);
+  const int gt = pick_head_tile(group, kv_dtype);
   const int head_tiles = ceil_div(group, gt);
   const uint32_t gdy = (uint32_t)(num_kv_heads * head_tiles);
   const uint32_t max_grid =
@@ -226,7 +227,7 @@ namespace fi {
 static int fill_common(DecodeKernelParams& kp, int kv_dt, int head_dim, int num_qo_heads,
                        int num_kv_heads, int page_size) {
   const int group = num_qo_heads / num_kv_heads;
-  const int gt = pick_head_tile(group);
+  const int gt = pick_head_tile(group, kv_dt);
   kp.num_qo_heads = num_qo_heads;
   kp.num_kv_heads = num_kv_heads;
   kp.group_size = group;

@@ -59,15 +59,22 @@ struct DecodeKernelParams {
   float rope_rcp_scale, rope_rcp_theta;
 };
 
+// K/V rows are read once per wave: non-temporal.  When a GQA group is processed as several head tiles the
+// neighbouring waves stream the SAME rows, so those loads stay temporal and the partner hits in L2.
+template <bool NT>
 __device__ __forceinline__ u32x4 load16(const void* base, int64_t byte_off) {
-  return __builtin_nontemporal_load((const u32x4*)((const char*)base + byte_off));
+  if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)((const char*)base + byte_off));
+  else return *(const u32x4*)((const char*)base + byte_off);
 }
 // uniform base + 32-bit per-lane byte offset (global_load ... saddr form)
+template <bool NT>
 __device__ __forceinline__ u32x4 load16(const char* ubase, uint32_t lane_byte_off) {
-  return __builtin_nontemporal_load((const u32x4*)(ubase + lane_byte_off));
+  if constexpr (NT) return __builtin_nontemporal_load((const u32x4*)(ubase + lane_byte_off));
+  else return *(const u32x4*)(ubase + lane_byte_off);
 }
 
-template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD>
+// NT: non-temporal K/V loads (false when several head tiles stream the same rows)
+template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD, bool NT = true>
 struct DecodeWave {
   using T = KVTraits<KV_DT>;
   static constexpr int VEC = T::VEC;
@@ -129,16 +136,16 @@ struct DecodeWave {
         const int entry0 = tok0 & (p.page_size - 1);
         const int64_t sbase =
             ((int64_t)page * p.kv_stride_page + head_off + (int64_t)entry0 * p.kv_stride_n) * T::BYTES;
-        b.k[j] = load16((const char*)p.k + sbase, lane_voff);
-        b.v[j] = load16((const char*)p.v + sbase, lane_voff);
+        b.k[j] = load16<NT>((const char*)p.k + sbase, lane_voff);
+        b.v[j] = load16<NT>((const char*)p.v + sbase, lane_voff);
       } else {
         const int tok = min(tok0 + r, chunk_end - 1);
         const int pi = (int)fast_div((uint32_t)tok, p.page_div);
         const int entry = tok - pi * p.page_size;
         const int64_t off = (int64_t)pg[j] * p.kv_stride_page + head_off +
                             (int64_t)entry * p.kv_stride_n + (int64_t)(c * VEC);
-        b.k[j] = load16(p.k, off * T::BYTES);
-        b.v[j] = load16(p.v, off * T::BYTES);
+        b.k[j] = load16<NT>(p.k, off * T::BYTES);
+        b.v[j] = load16<NT>(p.v, off * T::BYTES);
       }
     }
   }
@@ -477,13 +484,13 @@ struct DecodeWave {
   }
 };
 
-template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD>
+template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD, bool NT = true>
 __global__ void __launch_bounds__(kDecodeThreads, 2)
     batch_decode_kernel(const DecodeKernelParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int item = blockIdx.x * kDecodeWaves + wave;
   if (item >= p.num_items) return;
-  DecodeWave<KV_DT, HEAD_DIM, GT, ROPE, FAST, NLOAD> w(p);
+  DecodeWave<KV_DT, HEAD_DIM, GT, ROPE, FAST, NLOAD, NT> w(p);
   w.run(item);
 }
 

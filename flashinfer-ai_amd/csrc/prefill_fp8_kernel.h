@@ -33,8 +33,11 @@ __device__ __forceinline__ f32x16 mfma_fp8_k64(i32x8 a, i32x8 b, f32x16 c) {
 }
 
 // OUT16: output dtype (FI_DTYPE_F16 / FI_DTYPE_BF16); head_dim 128; page_size % 4 == 0
+#ifndef FI_FP8_WAVES_PER_SIMD
+#define FI_FP8_WAVES_PER_SIMD 2
+#endif
 template <int OUT16>
-__global__ void __launch_bounds__(kPrefillThreads, 2)
+__global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     batch_prefill_fp8_kernel(const PrefillKernelParams p) {
   constexpr int D = 128;
   constexpr int K_ROWB = 128;               // bytes per row of the K image (one kv row)

@@ -18,7 +18,7 @@ def ceil_div(a: int, b: int) -> int:
     return (a + b - 1) // b
 
 
-def pick_head_tile(group_size: int) -> int:
+def pick_head_tile(group_size: int, kv_bytes: int = 2) -> int:
     if group_size <= 1:
         return 1
     if group_size == 2:
@@ -39,10 +39,10 @@ def partition_pages(max_grid: int, gdy: int, num_pages: List[int], min_pages: in
 
 
 def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, page_size: int,
-                    max_grid: int, enable_cuda_graph: bool = False):
+                    max_grid: int, enable_cuda_graph: bool = False, kv_bytes: int = 2):
     batch = len(indptr) - 1
     group = num_qo_heads // num_kv_heads
-    gdy = num_kv_heads * ceil_div(group, pick_head_tile(group))
+    gdy = num_kv_heads * ceil_div(group, pick_head_tile(group, kv_bytes))
     num_pages = [indptr[i + 1] - indptr[i] for i in range(batch)]
     if batch * gdy >= max_grid:
         split, chunk_pages, new_batch = False, max(num_pages + [1]), batch
