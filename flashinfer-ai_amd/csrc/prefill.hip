@@ -163,8 +163,10 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   const fi_paged_kv_t& kv = a->kv;
   const int64_t num_work = plan_info[FI_PP_PADDED_BATCH_SIZE];
   if (num_work == 0 || kv.batch_size == 0) return 0;
-  FI_REQUIRE(a->q && a->o && a->qo_indptr && kv.k_data && kv.v_data && kv.indptr && kv.last_page_len,
+  // kv.indices == NULL && kv.last_page_len == NULL: ragged KV (identity page table, every page full)
+  FI_REQUIRE(a->q && a->o && a->qo_indptr && kv.k_data && kv.v_data && kv.indptr,
              "batch_prefill_paged_run: null tensor");
+  FI_REQUIRE(kv.last_page_len || !kv.indices, "batch_prefill_paged_run: a page table needs last_page_len");
   FI_REQUIRE(kv.batch_size == plan_info[6], "batch_prefill_paged_run: batch size differs from the plan");
   FI_REQUIRE(kv.num_kv_heads > 0 && a->num_qo_heads % kv.num_kv_heads == 0,
              "batch_prefill_paged_run: num_qo_heads must be a multiple of num_kv_heads");

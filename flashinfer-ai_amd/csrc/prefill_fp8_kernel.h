@@ -82,7 +82,9 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   if (p.kv_indptr) {
     page_begin = p.kv_indptr[req];
     const int np = p.kv_indptr[req + 1] - page_begin;
-    kv_len = np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0;
+    // ragged KV (no last_page_len): every page is full (ref ragged wrapper: prefill.py:2255-3007)
+    kv_len = p.kv_last_page_len ? (np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0)
+                                : np * p.page_size;
   } else {
     kv_len = p.single_kv_len;
   }
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
       const int kvi = max(min(tile * kTileKV + row, kv_len - 1), 0);
       const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
       en[i] = kvi - pi * p.page_size;
-      pg[i] = p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
+      pg[i] = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
     }
   };
   struct Stage {

@@ -205,7 +205,9 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   if (p.kv_indptr) {
     page_begin = p.kv_indptr[req];
     const int np = p.kv_indptr[req + 1] - page_begin;
-    kv_len = np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0;
+    // ragged KV (no last_page_len): every page is full (ref ragged wrapper: prefill.py:2255-3007)
+    kv_len = p.kv_last_page_len ? (np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0)
+                                : np * p.page_size;
   } else {
     kv_len = p.single_kv_len;
   }
@@ -308,7 +310,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
       const int kvi = max(min(tile * kTileKV + ps * RPP + st_row, kv_len - 1), 0);
       const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
       en[ps] = kvi - pi * p.page_size;
-      pg[ps] = p.kv_indices ? p.kv_indices[page_begin + pi] : pi;
+      pg[ps] = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
     }
   };
   // One register set stages K and then V of the next tile (K is written to LDS -- the OTHER buffer, free

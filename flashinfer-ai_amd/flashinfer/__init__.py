@@ -32,9 +32,26 @@ from .page import get_seq_lens as get_seq_lens
 from .prefill import (
     BatchPrefillWithPagedKVCacheWrapper as BatchPrefillWithPagedKVCacheWrapper,
 )
+from .prefill import (
+    BatchPrefillWithRaggedKVCacheWrapper as BatchPrefillWithRaggedKVCacheWrapper,
+)
 from .prefill import single_prefill_with_kv_cache as single_prefill_with_kv_cache
 from .prefill import (
     single_prefill_with_kv_cache_return_lse as single_prefill_with_kv_cache_return_lse,
+)
+from .rope import apply_llama31_rope as apply_llama31_rope
+from .rope import apply_llama31_rope_inplace as apply_llama31_rope_inplace
+from .rope import apply_llama31_rope_pos_ids as apply_llama31_rope_pos_ids
+from .rope import (
+    apply_llama31_rope_pos_ids_inplace as apply_llama31_rope_pos_ids_inplace,
+)
+from .rope import apply_rope as apply_rope
+from .rope import apply_rope_inplace as apply_rope_inplace
+from .rope import apply_rope_pos_ids as apply_rope_pos_ids
+from .rope import apply_rope_pos_ids_inplace as apply_rope_pos_ids_inplace
+from .rope import apply_rope_with_cos_sin_cache as apply_rope_with_cos_sin_cache
+from .rope import (
+    apply_rope_with_cos_sin_cache_inplace as apply_rope_with_cos_sin_cache_inplace,
 )
 from .utils import next_positive_power_of_2 as next_positive_power_of_2
 

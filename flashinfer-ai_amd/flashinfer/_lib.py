@@ -160,6 +160,18 @@ class SinglePrefillParams(C.Structure):
     ]
 
 
+class RopeParams(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("k", C.c_void_p), ("q_out", C.c_void_p), ("k_out", C.c_void_p),
+        ("pos_ids", C.c_void_p), ("cos_sin_cache", C.c_void_p),
+        ("q_stride_n", C.c_int64), ("q_stride_h", C.c_int64), ("k_stride_n", C.c_int64), ("k_stride_h", C.c_int64),
+        ("qo_stride_n", C.c_int64), ("qo_stride_h", C.c_int64), ("ko_stride_n", C.c_int64), ("ko_stride_h", C.c_int64),
+        ("nnz", C.c_int32), ("num_q_heads", C.c_int32), ("num_k_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("rotary_dim", C.c_int32), ("interleave", C.c_int32), ("dtype", C.c_int32),
+        ("rope_rcp_scale", C.c_float), ("rope_rcp_theta", C.c_float), ("smooth_a", C.c_float), ("smooth_b", C.c_float),
+    ]
+
+
 FI_PREFILL_PLAN_INFO_LEN = 16
 
 _lib: Optional[C.CDLL] = None
@@ -183,6 +195,8 @@ EXPORTED_SYMBOLS = [
     "fi_group_gemm_fp8_nt_groupwise",
     "fi_get_batch_indices_positions",
     "fi_append_paged_kv_cache",
+    "fi_apply_rope_pos_ids",
+    "fi_rope_positions_from_indptr",
 ]
 
 
@@ -215,6 +229,8 @@ def lib() -> C.CDLL:
     l.fi_group_gemm_fp8_nt_groupwise.argtypes = [vp] * 6 + [i32] * 11 + [vp]
     l.fi_get_batch_indices_positions.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     l.fi_append_paged_kv_cache.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp, i32, C.POINTER(PagedKV), vp]
+    l.fi_apply_rope_pos_ids.argtypes = [C.POINTER(RopeParams), vp]
+    l.fi_rope_positions_from_indptr.argtypes = [vp, vp, i32, i32, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(l, name)
         if name not in ("fi_last_error",):

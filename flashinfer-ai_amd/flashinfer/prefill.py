@@ -529,3 +529,249 @@ class BatchPrefillWithPagedKVCacheWrapper:
     def end_forward(self) -> None:
         r"""Warning: this function is deprecated and has no effect."""
         pass
+
+
+class BatchPrefillWithRaggedKVCacheWrapper:
+    r"""Prefill / append attention with ragged (tensor) KV for a batch of requests: ``k``/``v`` are
+    ``[kv_indptr[-1], num_kv_heads, head_dim]`` (``NHD``) or ``[num_kv_heads, kv_indptr[-1], head_dim]`` (``HND``).
+
+    Runs the paged kernels with an identity page table of one-token pages (see include/fi_mi355.h).
+    (ref: flashinfer/prefill.py:2255-3007)
+    """
+
+    def __init__(
+        self,
+        float_workspace_buffer: torch.Tensor,
+        kv_layout: str = "NHD",
+        use_cuda_graph: bool = False,
+        qo_indptr_buf: Optional[torch.Tensor] = None,
+        kv_indptr_buf: Optional[torch.Tensor] = None,
+        custom_mask_buf: Optional[torch.Tensor] = None,
+        mask_indptr_buf: Optional[torch.Tensor] = None,
+        backend: str = "auto",
+        jit_args: Optional[List[Any]] = None,
+        jit_kwargs: Optional[dict] = None,
+    ) -> None:
+        _check_kv_layout(kv_layout)
+        if jit_args is not None:
+            raise ValueError("jit_args is not supported: kernels are built ahead of time")
+        if backend not in ("auto", "fa2", "fa3"):
+            raise ValueError(f"backend {backend!r} is not available on MI355X (use 'auto')")
+        _lib.require_gpu_tensor(float_workspace_buffer, "float_workspace_buffer")
+        self._kv_layout = kv_layout
+        self._float_workspace_buffer = float_workspace_buffer
+        self.device = float_workspace_buffer.device
+        self._int_workspace_buffer = torch.empty((8 * 1024 * 1024,), dtype=torch.uint8, device=self.device)
+        self._pin_memory_int_workspace_buffer = torch.empty(
+            self._int_workspace_buffer.shape, dtype=torch.uint8, pin_memory=True, device="cpu"
+        )
+        self._use_cuda_graph = use_cuda_graph
+        if use_cuda_graph:
+            if not torch.is_tensor(qo_indptr_buf) or not torch.is_tensor(kv_indptr_buf):
+                raise ValueError("qo_indptr_buf and kv_indptr_buf should be torch.Tensor in cuda graph mode")
+            self._fixed_batch_size = len(qo_indptr_buf) - 1
+            if len(kv_indptr_buf) != self._fixed_batch_size + 1:
+                raise ValueError("The length of kv_indptr_buf should be batch_size + 1.")
+        else:
+            self._fixed_batch_size = 0
+        self._qo_indptr_buf = qo_indptr_buf
+        self._kv_indptr_buf = kv_indptr_buf
+        self._plan_info = None
+
+    @property
+    def is_cuda_graph_enabled(self) -> bool:
+        return self._use_cuda_graph
+
+    def reset_workspace_buffer(self, float_workspace_buffer: torch.Tensor, int_workspace_buffer) -> None:
+        self._float_workspace_buffer = float_workspace_buffer
+        self._int_workspace_buffer = int_workspace_buffer
+        self._pin_memory_int_workspace_buffer = torch.empty(
+            self._int_workspace_buffer.shape, dtype=self._int_workspace_buffer.dtype, device="cpu", pin_memory=True
+        )
+
+    def plan(
+        self,
+        qo_indptr: torch.Tensor,
+        kv_indptr: torch.Tensor,
+        num_qo_heads: int,
+        num_kv_heads: int,
+        head_dim_qk: int,
+        head_dim_vo: Optional[int] = None,
+        custom_mask: Optional[torch.Tensor] = None,
+        packed_custom_mask: Optional[torch.Tensor] = None,
+        causal: bool = False,
+        pos_encoding_mode: str = "NONE",
+        use_fp16_qk_reduction: bool = False,
+        window_left: int = -1,
+        logits_soft_cap: Optional[float] = None,
+        sm_scale: Optional[float] = None,
+        rope_scale: Optional[float] = None,
+        rope_theta: Optional[float] = None,
+        q_data_type: Union[str, torch.dtype] = "float16",
+        kv_data_type: Optional[Union[str, torch.dtype]] = None,
+        non_blocking: bool = True,
+        prefix_len_ptr: Optional[torch.Tensor] = None,
+        token_pos_in_items_ptr: Optional[torch.Tensor] = None,
+        token_pos_in_items_len: int = 0,
+        max_item_len_ptr: Optional[torch.Tensor] = None,
+        fixed_split_size: Optional[int] = None,
+        disable_split_kv: bool = False,
+    ) -> None:
+        r"""Plan for ragged queries ``qo_indptr`` and ragged keys/values ``kv_indptr`` (both int32
+        ``[batch_size + 1]``).  Options as :meth:`BatchPrefillWithPagedKVCacheWrapper.plan`."""
+        if custom_mask is not None or packed_custom_mask is not None:
+            raise ValueError("custom masks are not supported by the MI355X backend yet")
+        if prefix_len_ptr is not None or token_pos_in_items_ptr is not None or max_item_len_ptr is not None:
+            raise ValueError("multi-item scoring is not supported by the MI355X backend")
+        for tensor, name in [(qo_indptr, "qo_indptr"), (kv_indptr, "kv_indptr")]:
+            if tensor.dtype != torch.int32:
+                raise ValueError(f"{name} must have dtype torch.int32, got {tensor.dtype}")
+        _check_pos_encoding_mode(pos_encoding_mode)
+        q_data_type = canonicalize_torch_dtype(q_data_type)
+        if kv_data_type is None:
+            kv_data_type = q_data_type
+        kv_data_type = canonicalize_torch_dtype(kv_data_type)
+        if logits_soft_cap is None:
+            logits_soft_cap = 0.0
+        if head_dim_vo is None:
+            head_dim_vo = head_dim_qk
+        batch_size = len(qo_indptr) - 1
+        if len(kv_indptr) != batch_size + 1:
+            raise ValueError("The kv_indptr length should be equal to qo_indptr length.")
+        qo_indptr_host = qo_indptr.to("cpu").contiguous()
+        kv_indptr_host = kv_indptr.to("cpu").contiguous()
+        kv_len_arr = (kv_indptr_host[1:] - kv_indptr_host[:-1]).to(torch.int32).contiguous()
+        total_num_rows = int(qo_indptr_host[-1])
+        if self.is_cuda_graph_enabled:
+            if batch_size != self._fixed_batch_size:
+                raise ValueError("The batch size should be fixed in cuda graph mode")
+            self._qo_indptr_buf.copy_(qo_indptr, non_blocking=non_blocking)
+            self._kv_indptr_buf.copy_(kv_indptr, non_blocking=non_blocking)
+        else:
+            self._qo_indptr_buf = qo_indptr.to(self.device, non_blocking=non_blocking)
+            self._kv_indptr_buf = kv_indptr.to(self.device, non_blocking=non_blocking)
+        plan_info = (C.c_int64 * _lib.FI_PREFILL_PLAN_INFO_LEN)()
+        with torch.cuda.device(self.device):
+            _lib.check(
+                _lib.lib().fi_batch_prefill_plan(
+                    self._float_workspace_buffer.data_ptr(),
+                    self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size(),
+                    self._int_workspace_buffer.data_ptr(), self._pin_memory_int_workspace_buffer.data_ptr(),
+                    self._int_workspace_buffer.numel(), qo_indptr_host.data_ptr(), kv_indptr_host.data_ptr(),
+                    kv_len_arr.data_ptr(), total_num_rows, batch_size, num_qo_heads, num_kv_heads, 1,
+                    int(self.is_cuda_graph_enabled), head_dim_qk, head_dim_vo, int(causal), window_left,
+                    -1 if fixed_split_size is None else fixed_split_size, int(disable_split_kv), plan_info,
+                    _lib.current_stream(self.device),
+                ),
+                "BatchPrefillWithRaggedKVCacheWrapper.plan",
+            )
+        self._plan_info = list(plan_info)
+        self._plan_info_c = plan_info
+        self._batch_size = batch_size
+        self._num_qo_heads = num_qo_heads
+        self._num_kv_heads = num_kv_heads
+        self._head_dim = head_dim_qk
+        self._total_num_rows = total_num_rows
+        self._total_kv_rows = int(kv_indptr_host[-1])
+        self._cached_q_data_type = q_data_type
+        self._cached_kv_data_type = kv_data_type
+        self._causal = causal
+        self._pos_encoding_mode = pos_encoding_mode
+        self._window_left = window_left
+        self._logits_soft_cap = logits_soft_cap
+        self._sm_scale = sm_scale
+        self._rope_scale = rope_scale
+        self._rope_theta = rope_theta
+
+    begin_forward = plan
+
+    def run(
+        self,
+        q: torch.Tensor,
+        k: torch.Tensor,
+        v: torch.Tensor,
+        *args,
+        q_scale: Optional[float] = None,
+        k_scale: Optional[float] = None,
+        v_scale: Optional[float] = None,
+        out: Optional[torch.Tensor] = None,
+        lse: Optional[torch.Tensor] = None,
+        return_lse: bool = False,
+        enable_pdl: Optional[bool] = None,
+    ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
+        r"""q ``[qo_indptr[-1], num_qo_heads, head_dim]``; k, v ragged as described in the class docstring."""
+        if self._plan_info is None:
+            raise RuntimeError("plan() must be called before run()")
+        if args:
+            raise ValueError("additional kernel arguments require jit_args, which is not supported")
+        for t, name in ((q, "q"), (k, "k"), (v, "v")):
+            _lib.require_gpu_tensor(t, name)
+        _check_cached_qkv_data_type(q, k, self._cached_q_data_type, self._cached_kv_data_type)
+        if is_float8(q):
+            raise ValueError("fp8 queries are supported by the paged wrapper only")
+        if k.shape != v.shape or k.stride() != v.stride() or k.dim() != 3 or k.stride(-1) != 1:
+            raise ValueError("k and v must be 3-D with equal shapes/strides, contiguous in head_dim")
+        if self._kv_layout == "NHD":
+            nnz_kv, num_kv_heads, head_dim = k.shape
+            stride_n, stride_h = k.stride(0), k.stride(1)
+        else:
+            num_kv_heads, nnz_kv, head_dim = k.shape
+            stride_h, stride_n = k.stride(0), k.stride(1)
+        if num_kv_heads != self._num_kv_heads or head_dim != self._head_dim or nnz_kv < self._total_kv_rows:
+            raise ValueError("k/v shape does not match the plan")
+        if q.dim() != 3 or q.shape[0] != self._total_num_rows or q.shape[1] != self._num_qo_heads:
+            raise ValueError("q shape does not match the plan")
+        if q.stride(-1) != 1:
+            q = q.contiguous()
+        logits_soft_cap = self._logits_soft_cap or 0.0
+        sm_scale = self._sm_scale if self._sm_scale is not None else 1.0 / math.sqrt(q.size(-1))
+        if q_scale is not None:
+            sm_scale *= q_scale
+        if k_scale is not None:
+            sm_scale *= k_scale
+        rope_scale = self._rope_scale or 1.0
+        rope_theta = self._rope_theta or 1e4
+        if return_lse:
+            if lse is None:
+                lse = torch.empty((q.size(0), q.size(1)), dtype=torch.float32, device=q.device)
+            else:
+                check_shape_dtype_device(lse, (q.size(0), q.size(1)), torch.float32, q.device, "lse")
+        if out is None:
+            out = torch.empty(q.shape[:-1] + v.shape[-1:], dtype=q.dtype, device=q.device)
+        else:
+            check_shape_dtype_device(out, q.shape[:-1] + v.shape[-1:], q.dtype, q.device, "out")
+        alibi = _get_cache_alibi_slopes_buf(q.shape[1], q.device) if self._pos_encoding_mode == "ALIBI" else None
+        params = _lib.BatchPrefillParams(
+            q=q.data_ptr(), q_stride_n=q.stride(0), q_stride_h=q.stride(1), qo_indptr=self._qo_indptr_buf.data_ptr(),
+            kv=_lib.PagedKV(
+                k_data=k.data_ptr(), v_data=v.data_ptr(), indptr=self._kv_indptr_buf.data_ptr(), indices=None,
+                last_page_len=None, rope_pos_offset=None, stride_page=stride_n, stride_n=stride_n, stride_h=stride_h,
+                page_size=1, num_kv_heads=num_kv_heads, head_dim=head_dim, batch_size=self._batch_size,
+                dtype=_lib.fi_dtype(k.dtype),
+            ),
+            o=out.data_ptr(), lse=_lib.ptr(lse) if return_lse else None, alibi_slopes=_lib.ptr(alibi),
+            scale_q=None, scale_k=None, scale_v=None, num_qo_heads=self._num_qo_heads,
+            q_dtype=_lib.fi_dtype(q.dtype), o_dtype=_lib.fi_dtype(q.dtype),
+            mask_mode=MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value,
+            pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=self._window_left,
+            logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
+            rope_rcp_theta=1.0 / rope_theta,
+        )
+        with torch.cuda.device(q.device):
+            _lib.check(
+                _lib.lib().fi_batch_prefill_paged_run(
+                    self._float_workspace_buffer.data_ptr(),
+                    self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size(),
+                    self._int_workspace_buffer.data_ptr(), self._int_workspace_buffer.numel(), self._plan_info_c,
+                    _lib.FI_PREFILL_PLAN_INFO_LEN, C.byref(params), _lib.current_stream(q.device),
+                ),
+                "BatchPrefillWithRaggedKVCacheWrapper.run",
+            )
+        if v_scale is not None:
+            out *= v_scale
+        return (out, lse) if return_lse else out
+
+    run_return_lse = functools.partialmethod(run, return_lse=True)
+
+    def end_forward(self) -> None:
+        pass

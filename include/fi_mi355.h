@@ -246,6 +246,9 @@ typedef struct fi_batch_prefill_params {
   float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
 } fi_batch_prefill_params_t;
 
+/* Ragged (non-paged) KV, ref BatchPrefillWithRaggedKVCacheRun csrc/batch_prefill.cu:76-197: pass the
+ * [nnz_kv, H, D] tensors as a cache with page_size = 1, stride_page = stride_n, kv.indptr = the ragged
+ * kv_indptr, kv.indices = NULL (identity) and kv.last_page_len = NULL (all pages full). */
 FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws_bytes, void* int_ws, size_t int_ws_bytes,
                                const int64_t* plan_info, int32_t plan_info_len,
                                const fi_batch_prefill_params_t* params, fi_stream_t stream);
@@ -308,6 +311,34 @@ FI_API int fi_append_paged_kv_cache(const void* append_key, const void* append_v
                              int64_t k_stride_h, int64_t v_stride_n, int64_t v_stride_h,
                              const int32_t* batch_indices, const int32_t* positions, int32_t nnz,
                              const fi_paged_kv_t* kv, fi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Standalone rotary embedding (SURVEY.md 8f "next" row).  ref: apply_rope / apply_rope_pos_ids /
+ * apply_llama31_rope* / apply_rope_pos_ids_cos_sin_cache in csrc/rope.cu, include/flashinfer/pos_enc.cuh:465-1070,
+ * flashinfer/rope.py:321-1150.  One entry point: positions are explicit (fi_rope_positions_from_indptr
+ * expands the (indptr, offsets) form), llama-3.1 scaling enters through smooth_a / smooth_b
+ * (pos_enc.cuh:976-977; 0, 0 = plain RoPE), cos_sin_cache != NULL selects the table form.
+ * q/k: [nnz, heads, head_dim] f16/bf16 with element strides; q_out/k_out may alias q/k (in place).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct fi_rope_params {
+  const void* q;
+  const void* k;
+  void* q_out;
+  void* k_out;
+  const int32_t* pos_ids;     /* [nnz] device */
+  const float* cos_sin_cache; /* optional [max_pos, rotary_dim] f32: cos half | sin half */
+  int64_t q_stride_n, q_stride_h, k_stride_n, k_stride_h;
+  int64_t qo_stride_n, qo_stride_h, ko_stride_n, ko_stride_h;
+  int32_t nnz, num_q_heads, num_k_heads, head_dim, rotary_dim;
+  int32_t interleave; /* 1: pairs (2i, 2i+1); 0: pairs (i, i + rotary_dim/2) */
+  int32_t dtype;
+  float rope_rcp_scale, rope_rcp_theta, smooth_a, smooth_b;
+} fi_rope_params_t;
+
+FI_API int fi_apply_rope_pos_ids(const fi_rope_params_t* params, fi_stream_t stream);
+/* pos_ids[i] = offsets[b] + i - indptr[b] for indptr[b] <= i < indptr[b+1] (ref: pos_enc.cuh:540-575) */
+FI_API int fi_rope_positions_from_indptr(const int32_t* indptr, const int32_t* offsets, int32_t batch_size,
+                                  int32_t nnz, int32_t* pos_ids, fi_stream_t stream);
 
 #ifdef __cplusplus
 }

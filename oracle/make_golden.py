@@ -49,6 +49,39 @@ def main():
         data[f"alibi_{tag}_slopes"] = alibi_reference.get_slopes(h).numpy()
     np.savez_compressed(OUT, **data)
     print("wrote", os.path.abspath(OUT), {k: v.shape for k, v in data.items()})
+    rope_family(g)
+
+
+def rope_family(g):
+    """tests/golden/rope_family_golden.npz: the standalone RoPE family against rope_reference.py
+    (the flows of tests/attention/test_rope.py:33-360, run on the CPU)."""
+    out = os.path.join(os.path.dirname(OUT), "rope_family_golden.npz")
+    data = {}
+    b, n, hq, hk, d, offset = 2, 9, 3, 2, 64, 5
+    for tag, rot, llama31 in (("plain_full", 64, False), ("plain_partial", 32, False), ("llama31_full", 64, True)):
+        q = torch.randn(b * n, hq, d, generator=g)
+        k = torch.randn(b * n, hk, d, generator=g)
+        theta = 5e5 if llama31 else 1e4
+        freqs_cis = rope_reference.precompute_freqs_cis(rot, n + offset, theta, use_scaled=llama31, device="cpu")
+        q_rot, k_rot = rope_reference.apply_rotary_emb(q.reshape(b, n, hq, d)[..., :rot], k.reshape(b, n, hk, d)[..., :rot],
+                                                       freqs_cis[offset: offset + n])
+        q_out = torch.cat([q_rot, q.reshape(b, n, hq, d)[..., rot:]], -1).reshape(b * n, hq, d)
+        k_out = torch.cat([k_rot, k.reshape(b, n, hk, d)[..., rot:]], -1).reshape(b * n, hk, d)
+        data[f"{tag}_q"], data[f"{tag}_k"] = q.numpy(), k.numpy()
+        data[f"{tag}_q_out"], data[f"{tag}_k_out"] = q_out.numpy(), k_out.numpy()
+        data[f"{tag}_meta"] = np.array([b, n, offset, rot, theta, float(llama31)], dtype=np.float64)
+    # cos/sin cache form (vLLM-style module, neox and gpt-j pairings, partial rotary)
+    for tag, neox, rot in (("cache_neox", True, 64), ("cache_gptj", False, 32)):
+        emb = rope_reference.RotaryEmbedding(d, rot, 64, 10000, neox, torch.float32, device="cpu")
+        pos = torch.randint(0, 64, (11,), generator=g)
+        q = torch.randn(11, hq * d, generator=g)
+        k = torch.randn(11, hk * d, generator=g)
+        q_out, k_out = emb.forward_native(pos, q.clone(), k.clone())
+        data[f"{tag}_q"], data[f"{tag}_k"], data[f"{tag}_pos"] = q.numpy(), k.numpy(), pos.numpy()
+        data[f"{tag}_cache"] = emb.cos_sin_cache.numpy()
+        data[f"{tag}_q_out"], data[f"{tag}_k_out"] = q_out.numpy(), k_out.numpy()
+    np.savez_compressed(out, **data)
+    print("wrote", os.path.abspath(out))
 
 
 if __name__ == "__main__":

@@ -239,3 +239,33 @@ def test_full_size_c2_split_invariance():
             torch.arange(len(pages), dtype=torch.int32), last[r:r + 1].cpu())
         torch.testing.assert_close(o_split[r].float().cpu(), o_ref[0].float(), **tol(torch.bfloat16))
         torch.testing.assert_close(lse_split[r].cpu(), lse_ref[0].float(), rtol=1e-3, atol=1e-3)
+
+
+def test_run_is_graph_capturable():
+    """run() issues only kernel launches on the current stream, so it can be captured into a hipGraph and
+    replayed (ref: CUDA-graph mode, tests/attention/test_batch_decode_kernels.py:503)."""
+    import flashinfer
+
+    hq, hkv, d, ps, b = 8, 2, 128, 16, 4
+    kv_lens = [300, 40, 1000, 77]
+    cache, indptr, indices, last = make_paged(b, kv_lens, ps, hkv, d, torch.float16, "NHD", seed=12)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.CUDAGraphBatchDecodeWithPagedKVCacheWrapper(
+        ws, torch.empty(b + 1, dtype=torch.int32, device=DEV), torch.empty(512, dtype=torch.int32, device=DEV),
+        torch.empty(b, dtype=torch.int32, device=DEV), "NHD")
+    w.plan(indptr, indices, last, hq, hkv, d, ps, q_data_type=torch.float16)
+    q = torch.randn(b, hq, d).half().to(DEV)
+    cd = cache.to(DEV)
+    out = torch.empty_like(q)
+    w.run(q, cd, out=out)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        w.run(q, cd, out=out)
+    # new query values in the same buffers, then replay
+    q.copy_(torch.randn(b, hq, d).half())
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    o_ref, _ = R.batch_decode_ref(q.float().cpu(), cache.float(), "NHD", indptr, indices, last)
+    torch.testing.assert_close(out.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)

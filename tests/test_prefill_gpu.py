@@ -232,3 +232,31 @@ def test_fp8_native_kernel_matches_upcast_kernel():
                           scale_v=sv.to(DEV)))
     torch.testing.assert_close(outs[0][0].float(), outs[1][0].float(), rtol=2e-3, atol=2e-3)
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("layout", ["NHD", "HND"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_ragged_kv_prefill_wrapper(layout, causal):
+    # ref: BatchPrefillWithRaggedKVCacheWrapper, flashinfer/prefill.py:2255-3007
+    import flashinfer
+
+    torch.manual_seed(9)
+    hq, hkv, d = 8, 2, 128
+    qo_lens, kv_lens = [5, 130, 1, 64], [33, 130, 7, 200]
+    q = torch.randn(sum(qo_lens), hq, d).half()
+    k = torch.randn(sum(kv_lens), hkv, d).half()
+    v = torch.randn(sum(kv_lens), hkv, d).half()
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    kv_indptr = torch.tensor([0] + list(torch.tensor(kv_lens).cumsum(0)), dtype=torch.int32)
+    ws = torch.zeros(16 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithRaggedKVCacheWrapper(ws, layout)
+    w.plan(qo_indptr.to(DEV), kv_indptr.to(DEV), hq, hkv, d, causal=causal)
+    kd, vd = (k.to(DEV), v.to(DEV)) if layout == "NHD" else (k.transpose(0, 1).contiguous().to(DEV), v.transpose(0, 1).contiguous().to(DEV))
+    o, lse = w.run(q.to(DEV), kd, vd, return_lse=True)
+    for b in range(4):
+        qs = q[int(qo_indptr[b]):int(qo_indptr[b + 1])].float()
+        ks = k[int(kv_indptr[b]):int(kv_indptr[b + 1])].float()
+        vs = v[int(kv_indptr[b]):int(kv_indptr[b + 1])].float()
+        o_ref, lse_ref = R.attention_ref(qs, ks, vs, causal=causal)
+        torch.testing.assert_close(o[int(qo_indptr[b]):int(qo_indptr[b + 1])].float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(lse[int(qo_indptr[b]):int(qo_indptr[b + 1])].cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
