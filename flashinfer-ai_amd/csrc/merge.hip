@@ -5,14 +5,17 @@ namespace fi {
 
 // Merge n states per (row, head).  Ragged layout [nnz, H, D] (ref: VariableLengthMergeStates,
 // cascade.cuh:366-467) or dense [row, n, H, D] (ref: MergeStates, cascade.cuh:213-256).
-// Two passes so that no load depends on a previous one: (1) the n log-sum-exp values are read 64 at a
-// time, one per lane, and reduced to the row maximum and the weights' sum; (2) the value rows are
-// streamed with the weight of entry j broadcast from lane j.
+// One WORKGROUP (4 waves) per (row, head).  Two passes so that no load depends on a previous one:
+// (1) every wave reads the n log-sum-exp values 64 at a time, one per lane, and reduces them to the row
+// maximum; (2) the value rows are split over the four waves (entry j -> wave j % 4), streamed with the
+// weight of entry j broadcast from its lane, and the four partial sums are combined through LDS.  Long
+// context / small batch decode merges hundreds of split-KV partials per head, which a single wave would
+// read as one latency-bound chain.
 __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNParams p) {
+  __shared__ float red[kMergeWaves][kMergeMaxPerLane + 1][64];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * kMergeWaves + wave;
-  if (item >= (int64_t)p.seq_len * p.num_heads) return;
+  const int64_t item = blockIdx.x;
   const int row = (int)(item / p.num_heads);
   const int head = (int)(item % p.num_heads);
   int64_t first;
@@ -25,7 +28,7 @@ __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNPara
     n = p.n_fixed;
   }
   const int D = p.head_dim;
-  // pass 1: maximum
+  // pass 1: maximum (every wave computes it: n floats, L2-resident)
   float mx = -1.0e30f;
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
@@ -37,14 +40,14 @@ __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNPara
 #pragma unroll
   for (int k = 0; k < kMergeMaxPerLane; ++k) acc[k] = 0.f;
   float dsum = 0.f;
-  // pass 2
+  // pass 2: this wave owns entries j with j % 4 == wave inside each group of 64
   for (int j0 = 0; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     const float w_lane = j < n ? fast_exp2(p.s[(first + j) * p.num_heads + head] - mx) : 0.f;
-    dsum += w_lane;
+    if (wave == 0) dsum += w_lane;
     const int cnt = min(64, n - j0);
 #pragma unroll 4
-    for (int jj = 0; jj < cnt; ++jj) {
+    for (int jj = wave; jj < cnt; jj += kMergeWaves) {
       const float w = __shfl(w_lane, jj, 64);
       const int64_t e = (first + j0 + jj) * p.num_heads + head;
 #pragma unroll
@@ -53,6 +56,17 @@ __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNPara
         if (i < D) acc[k] += w * load_any_float(p.v, e * D + i, p.in_dtype);
       }
     }
+  }
+  if (n > 1) {
+#pragma unroll
+    for (int k = 0; k < kMergeMaxPerLane; ++k) red[wave][k][lane] = acc[k];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int k = 0; k < kMergeMaxPerLane; ++k)
+      acc[k] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+  } else if (wave != 0) {
+    return;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
@@ -97,7 +111,7 @@ __global__ void __launch_bounds__(kMergeThreads) merge_2_kernel(const Merge2Para
 hipError_t launch_merge_n(const MergeNParams& p, hipStream_t stream) {
   const int64_t items = (int64_t)p.seq_len * p.num_heads;
   if (items == 0) return hipSuccess;
-  const int grid = (int)((items + kMergeWaves - 1) / kMergeWaves);
+  const int grid = (int)items;  // one workgroup per (row, head)
   merge_n_kernel<<<dim3(grid), dim3(kMergeThreads), 0, stream>>>(p);
   return hipGetLastError();
 }
