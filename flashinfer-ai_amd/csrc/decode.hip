@@ -61,6 +61,19 @@ static int pick_head_tile(int group_size, int kv_dt = FI_DTYPE_BF16) {
   return t < max_tile ? t : max_tile;
 }
 
+// Matrix-core decode (decode_mfma_kernel.h): groups too wide for the VALU kernel, K/V stored in the q
+// dtype.  FI_DECODE_MFMA_MIN_GROUP moves the crossover (0 disables the path).
+hipError_t decode_mfma_launch(const DecodeKernelParams& p, int dtype, int head_dim, int grid,
+                              hipStream_t stream);
+static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim) {
+  static const int min_group = [] {
+    const char* e = getenv("FI_DECODE_MFMA_MIN_GROUP");
+    return e ? atoi(e) : 5;
+  }();
+  return min_group > 0 && group_size >= min_group && group_size <= 32 && q_dt == kv_dt &&
+         (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) && (head_dim == 64 || head_dim == 128);
+}
+
 static int tokens_per_load(int kv_dt, int head_dim) {
   const int vec = 16 / (int)dtype_size(kv_dt);
   return 64 / (head_dim / vec);
@@ -128,7 +141,9 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
 
   const int group = num_qo_heads / num_kv_heads;
   const int gt = pick_head_tile(group, kv_dtype);
-  const int head_tiles = ceil_div(group, gt);
+  // the matrix-core kernel covers the whole group with one wave; a run() that cannot use it (rope, alibi,
+  // soft cap, window) still works on this plan, with head_tiles x the work items
+  const int head_tiles = mfma_decode_shape(group, q_dtype, kv_dtype, head_dim) ? 1 : ceil_div(group, gt);
   const uint32_t gdy = (uint32_t)(num_kv_heads * head_tiles);
   // head tiles of one kv head stream the same rows (the partner wave's loads hit in L2), so a multi-tile
   // launch is sized for twice the waves: measured 4.42 vs 3.73 TB/s at Hq/Hkv = 64/8 (r1)
@@ -309,6 +324,10 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   kp.kv_stride_page = kv.stride_page;
   kp.kv_stride_n = kv.stride_n;
   kp.kv_stride_h = kv.stride_h;
+  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim) &&
+                        a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
+                        a->window_left < 0 && kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
+  if (use_mfma) kp.head_tiles = 1;
   kp.num_items = (int32_t)(padded * kv.num_kv_heads * kp.head_tiles);
   kp.kv_chunk_size = (int32_t)plan_info[FI_DP_KV_CHUNK_SIZE];
   kp.split_kv = split;
@@ -332,7 +351,10 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
                  kp.window_left < 0 && !getenv("FI_DECODE_FORCE_GENERIC");
   if (kp.num_items > 0) {
     const int grid = ceil_div(kp.num_items, kDecodeWaves);
-    FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
+    if (use_mfma)
+      FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, kv.head_dim, grid, stream));
+    else
+      FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
   }
   if (split) {
     // ref: VariableLengthMergeStates after the partition-kv kernel, decode.cuh:798-821

@@ -159,13 +159,10 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
         s_acc = M::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc);
       }
       if (tile0 + kDmTileKV > chunk_end) {
-        const unsigned span = (unsigned)(chunk_end - 1 - tile0 - 4 * lh);
+        // tail tile: accumulator register r of lane (q, lh) is kv row 8 (r >> 2) + 4 lh + (r & 3)
+        const int left = chunk_end - tile0 - 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const unsigned rel = (unsigned)((r & 3) + 8 * (r >> 2));
-          s_acc[r] = (4 * lh + (int)rel < chunk_end - tile0) ? s_acc[r] : -INFINITY;
-        }
-        (void)span;
+        for (int r = 0; r < 16; ++r) s_acc[r] = ((r & 3) + 8 * (r >> 2) < left) ? s_acc[r] : -INFINITY;
       }
       // ---- online softmax (base 2) ----
       float mx = s_acc[0];

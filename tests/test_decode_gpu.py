@@ -64,6 +64,39 @@ def test_batch_decode_matches_oracle(dtype, layout, page_size, hq, hkv):
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("page_size", [5, 16])
+@pytest.mark.parametrize("hq,hkv", [(64, 8), (32, 2), (64, 2), (40, 8), (26, 2)])
+def test_batch_decode_wide_groups_matrix_core_path(dtype, d, page_size, hq, hkv):
+    """Groups of 5..32 query heads per kv head run on the MFMA decode kernel (decode_mfma_kernel.h); the
+    reference's counterpart is use_tensor_cores=True (tests/attention/test_tensor_cores_decode.py)."""
+    kv_lens = [1, 31, 32, 33, 777, 4096, 64, 2500, 95]
+    torch.manual_seed(17)
+    layout = "NHD" if page_size == 16 else "HND"
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, page_size, hkv, d, dtype, layout, seed=23)
+    q = torch.randn(len(kv_lens), hq, d).to(dtype)
+    (o, lse), _ = run_batch_decode(q, cache, layout, indptr, indices, last, hq, hkv, d, page_size)
+    o_ref, lse_ref = R.batch_decode_ref(q.float(), cache.float(), layout, indptr, indices, last)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), **tol(dtype))
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_batch_decode_wide_group_no_split_and_graph_padding():
+    # enough requests that the planner does not split (one wave per request x kv head), then the padded
+    # CUDA-graph style plan of the same shape
+    hq, hkv, d, page_size = 64, 8, 128, 16
+    kv_lens = [((37 * i) % 300) + 1 for i in range(320)]
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, page_size, hkv, d, torch.float16, "NHD", seed=29)
+    torch.manual_seed(31)
+    q = torch.randn(len(kv_lens), hq, d).half()
+    o_ref, lse_ref = R.batch_decode_ref(q.float(), cache.float(), "NHD", indptr, indices, last)
+    (o, lse), w = run_batch_decode(q, cache, "NHD", indptr, indices, last, hq, hkv, d, page_size)
+    assert w._plan_info[9] == 0  # split_kv off
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
 @pytest.mark.parametrize("d", [64, 128, 256])
 @pytest.mark.parametrize("kv_dtype", [torch.float16, torch.float8_e4m3fn, torch.float8_e5m2])
 def test_batch_decode_head_dims_and_fp8_kv(d, kv_dtype):
