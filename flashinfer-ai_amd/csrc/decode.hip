@@ -63,14 +63,22 @@ static int pick_head_tile(int group_size, int kv_dt = FI_DTYPE_BF16) {
 
 // Matrix-core decode (decode_mfma_kernel.h): groups too wide for the VALU kernel, K/V stored in the q
 // dtype.  FI_DECODE_MFMA_MIN_GROUP moves the crossover (0 disables the path).
-hipError_t decode_mfma_launch(const DecodeKernelParams& p, int dtype, int head_dim, int grid,
+hipError_t decode_mfma_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int grid,
                               hipStream_t stream);
 static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim) {
   static const int min_group = [] {
     const char* e = getenv("FI_DECODE_MFMA_MIN_GROUP");
     return e ? atoi(e) : 5;
   }();
-  return min_group > 0 && group_size >= min_group && group_size <= 32 && q_dt == kv_dt &&
+  static const int min_group_fp8 = [] {
+    // an fp8 cache doubles the VALU work per byte: measured 5.0 (VALU) vs 6.35 TB/s (MFMA) at G = 4,
+    // 6.6 vs 6.4 TB/s at G = 1
+    const char* e = getenv("FI_DECODE_MFMA_MIN_GROUP_FP8");
+    return e ? atoi(e) : 3;
+  }();
+  const bool fp8 = kv_dt == FI_DTYPE_FP8_E4M3 || kv_dt == FI_DTYPE_FP8_E5M2;
+  const int mg = fp8 ? min_group_fp8 : min_group;
+  return mg > 0 && group_size >= mg && group_size <= 32 && (q_dt == kv_dt || fp8) &&
          (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) && (head_dim == 64 || head_dim == 128);
 }
 
@@ -352,7 +360,7 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   if (kp.num_items > 0) {
     const int grid = ceil_div(kp.num_items, kDecodeWaves);
     if (use_mfma)
-      FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, kv.head_dim, grid, stream));
+      FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, kv.dtype, kv.head_dim, grid, stream));
     else
       FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
   }
@@ -411,6 +419,10 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
 
+  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim) &&
+                        a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
+                        a->window_left < 0 && kp.kv_stride_page < (1ll << 31);
+  if (use_mfma) kp.head_tiles = 1;
   // split-KV so that the chip is filled (ref: decode.cuh:689-733, kv_len > 256 -> chunks >= 256)
   const int gdy = a->num_kv_heads * kp.head_tiles;
   const int max_grid = fi_num_compute_units() * decode_waves_per_cu();
@@ -436,7 +448,10 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
     kp.tmp_lse = (float*)((char*)tmp + vbytes);
   }
   const int grid = ceil_div(kp.num_items, kDecodeWaves);
-  FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
+  if (use_mfma)
+    FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, a->kv_dtype, a->head_dim, grid, stream));
+  else
+    FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
   if (kp.split_kv) {
     // partial states are [nchunks, Hq, D] == dense [row=1, n=nchunks, Hq, D]
     MergeNParams mp{kp.tmp_o, kp.tmp_lse, nullptr, a->o, a->lse, nchunks, 1,

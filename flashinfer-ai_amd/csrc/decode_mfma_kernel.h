@@ -18,13 +18,18 @@ namespace fi {
 
 constexpr int kDmTileKV = 32;
 
-template <int T16, int D>
+// T16: q/o (and MFMA) dtype; KVS: storage dtype of the cache (T16, or fp8 upcast to T16 while staging, as
+// the reference's decode does with an fp8 cache); PAGED: page table present (false: identity pages).
+template <int T16, int KVS, int D, bool PAGED>
 __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const DecodeKernelParams p) {
   using M = MfmaType<T16>;
   using frag_t = typename M::frag;
-  constexpr int ROWB = D * 2;
-  constexpr int CPR = D / 8;            // 16-byte chunks per row
-  constexpr int RPP = 64 / CPR;         // rows staged per pass by one wave
+  constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
+  constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
+  constexpr int ROWB = D * 2;           // bytes per row of the (16-bit) LDS images
+  constexpr int CPR = D / 8;            // 16-byte chunks per LDS row
+  constexpr int GCH = D * KV_BYTES / 16;  // 16-byte chunks per row in the cache
+  constexpr int RPP = 64 / GCH;         // rows staged per pass by one wave
   constexpr int NPASS = kDmTileKV / RPP;
   constexpr int KSTEPS = D / 16;
   constexpr int DBLK = D / 32;
@@ -73,8 +78,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
   const float c_log2 = p.sm_scale * kLog2e;
 
   // ---- staging: pass ps covers rows ps*RPP + lane/CPR, chunk lane%CPR ----
-  const int st_row = lane / CPR, st_ch = lane % CPR;
-  const int64_t thread_off = (int64_t)kv_head * p.kv_stride_h + st_ch * 8;
+  const int st_row = lane / GCH, st_ch = lane % GCH;
+  const int64_t thread_off = (int64_t)kv_head * p.kv_stride_h + st_ch * (16 / KV_BYTES);
   const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
   auto fetch_pages = [&](int tok0, int (&pg)[NPASS], int (&en)[NPASS]) {
 #pragma unroll
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
       const int kvi = max(min(tok0 + ps * RPP + st_row, chunk_end - 1), 0);
       const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
       en[ps] = kvi - pi * p.page_size;
-      pg[ps] = p.indices ? p.indices[page_begin + pi] : pi;
+      pg[ps] = PAGED ? p.indices[page_begin + pi] : pi;
     }
   };
   struct Stage {
@@ -93,8 +98,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
     for (int ps = 0; ps < NPASS; ++ps) {
       const int64_t off = (int64_t)((uint64_t)(uint32_t)pg[ps] * stride_page32 +
                                     (uint64_t)(uint32_t)en[ps] * stride_n32) + thread_off;
-      st.k[ps] = __builtin_nontemporal_load((const u32x4*)((const uint16_t*)p.k + off));
-      st.v[ps] = __builtin_nontemporal_load((const u32x4*)((const uint16_t*)p.v + off));
+      st.k[ps] = __builtin_nontemporal_load((const u32x4*)((const char*)p.k + off * KV_BYTES));
+      st.v[ps] = __builtin_nontemporal_load((const u32x4*)((const char*)p.v + off * KV_BYTES));
     }
   };
   auto k_lds_off = [&](int row, int ch) -> int {
@@ -109,8 +114,15 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + st_row;
-      *(u32x4*)(kb + k_lds_off(row, st_ch)) = st.k[ps];
-      *(u32x4*)(vb + v_lds_off(row, st_ch)) = st.v[ps];
+      if constexpr (KV_FP8) {  // 16 fp8 -> two 16-byte chunks of T16
+        *(u32x4*)(kb + k_lds_off(row, 2 * st_ch)) = fp8x8_to_16<T16, KVS>(u32x2{st.k[ps][0], st.k[ps][1]});
+        *(u32x4*)(kb + k_lds_off(row, 2 * st_ch + 1)) = fp8x8_to_16<T16, KVS>(u32x2{st.k[ps][2], st.k[ps][3]});
+        *(u32x4*)(vb + v_lds_off(row, 2 * st_ch)) = fp8x8_to_16<T16, KVS>(u32x2{st.v[ps][0], st.v[ps][1]});
+        *(u32x4*)(vb + v_lds_off(row, 2 * st_ch + 1)) = fp8x8_to_16<T16, KVS>(u32x2{st.v[ps][2], st.v[ps][3]});
+      } else {
+        *(u32x4*)(kb + k_lds_off(row, st_ch)) = st.k[ps];
+        *(u32x4*)(vb + v_lds_off(row, st_ch)) = st.v[ps];
+      }
     }
   };
   int k_rd[KSTEPS];

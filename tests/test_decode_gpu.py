@@ -82,6 +82,21 @@ def test_batch_decode_wide_groups_matrix_core_path(dtype, d, page_size, hq, hkv)
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("kv_dtype", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("qdtype", [torch.float16, torch.bfloat16])
+def test_batch_decode_wide_groups_fp8_cache(kv_dtype, d, qdtype):
+    hq, hkv, page_size = 32, 4, 16
+    kv_lens = [1, 33, 500, 3000, 64, 129]
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, page_size, hkv, d, kv_dtype, "NHD", seed=41)
+    torch.manual_seed(43)
+    q = torch.randn(len(kv_lens), hq, d).to(qdtype)
+    (o, lse), _ = run_batch_decode(q, cache, "NHD", indptr, indices, last, hq, hkv, d, page_size)
+    o_ref, lse_ref = R.batch_decode_ref(q.float(), cache.float(), "NHD", indptr, indices, last)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), **tol(qdtype))
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
 def test_batch_decode_wide_group_no_split_and_graph_padding():
     # enough requests that the planner does not split (one wave per request x kv head), then the padded
     # CUDA-graph style plan of the same shape
@@ -210,7 +225,7 @@ def test_cuda_graph_wrapper_fixed_shape_and_replan():
 
 @pytest.mark.parametrize("kv_len", [1, 54, 97, 512, 2048, 5000])
 @pytest.mark.parametrize("layout", ["NHD", "HND"])
-@pytest.mark.parametrize("hq,hkv", [(32, 32), (32, 8)])
+@pytest.mark.parametrize("hq,hkv", [(32, 32), (32, 8), (32, 4), (48, 2)])
 def test_single_decode_matches_oracle(kv_len, layout, hq, hkv):
     import flashinfer
 
