@@ -35,7 +35,7 @@ static bool use_fp8_native(const PrefillKernelParams& kp, int q_dt, int kv_dt, i
   }();
   return enabled && q_dt == FI_DTYPE_FP8_E4M3 && kv_dt == FI_DTYPE_FP8_E4M3 && head_dim == 128 &&
          kp.page_size % 4 == 0 && !rope && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
-         kp.window_left < 0;
+         kp.window_left < 0 && !kp.custom_mask;
 }
 
 static prefill_launch_fn find_prefill(int t16, int kvs, int qs, int d) {
@@ -170,8 +170,10 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   FI_REQUIRE(kv.batch_size == plan_info[6], "batch_prefill_paged_run: batch size differs from the plan");
   FI_REQUIRE(kv.num_kv_heads > 0 && a->num_qo_heads % kv.num_kv_heads == 0,
              "batch_prefill_paged_run: num_qo_heads must be a multiple of num_kv_heads");
-  FI_REQUIRE(a->mask_mode == FI_MASK_NON_CAUSAL || a->mask_mode == FI_MASK_CAUSAL,
-             "batch_prefill_paged_run: custom masks are not supported yet");
+  FI_REQUIRE(a->mask_mode >= FI_MASK_NON_CAUSAL && a->mask_mode <= FI_MASK_CUSTOM,
+             "batch_prefill_paged_run: bad mask_mode %d", a->mask_mode);
+  FI_REQUIRE(a->mask_mode != FI_MASK_CUSTOM || (a->custom_mask && a->mask_indptr),
+             "batch_prefill_paged_run: mask_mode CUSTOM needs custom_mask and mask_indptr");
   if (check_prefill_dtypes("batch_prefill_paged_run", a->q_dtype, kv.dtype, a->o_dtype)) return 1;
   const int t16 = compute_type(a->q_dtype, a->o_dtype);
   prefill_launch_fn fn = find_prefill(t16, kv.dtype, a->q_dtype, kv.head_dim);
@@ -220,6 +222,10 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.page_div = FastDiv((uint32_t)kv.page_size);
   kp.group_div = FastDiv((uint32_t)kp.group_size);
   kp.causal = a->mask_mode == FI_MASK_CAUSAL;
+  if (a->mask_mode == FI_MASK_CUSTOM) {
+    kp.custom_mask = a->custom_mask;
+    kp.mask_indptr = a->mask_indptr;
+  }
   kp.window_left = a->window_left;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
   kp.o_dtype = a->o_dtype;
@@ -245,8 +251,10 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   FI_REQUIRE(a->q && a->k && a->v && a->o, "single_prefill_run: null tensor");
   FI_REQUIRE(a->num_kv_heads > 0 && a->num_qo_heads % a->num_kv_heads == 0,
              "single_prefill_run: num_qo_heads must be a multiple of num_kv_heads");
-  FI_REQUIRE(a->mask_mode == FI_MASK_NON_CAUSAL || a->mask_mode == FI_MASK_CAUSAL,
-             "single_prefill_run: custom masks are not supported yet");
+  FI_REQUIRE(a->mask_mode >= FI_MASK_NON_CAUSAL && a->mask_mode <= FI_MASK_CUSTOM,
+             "single_prefill_run: bad mask_mode %d", a->mask_mode);
+  FI_REQUIRE(a->mask_mode != FI_MASK_CUSTOM || a->custom_mask,
+             "single_prefill_run: mask_mode CUSTOM needs custom_mask");
   if (check_prefill_dtypes("single_prefill_run", a->q_dtype, a->kv_dtype, a->o_dtype)) return 1;
   const int t16 = compute_type(a->q_dtype, a->o_dtype);
   prefill_launch_fn fn = find_prefill(t16, a->kv_dtype, a->q_dtype, a->head_dim);
@@ -290,6 +298,7 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   kp.single_qo_len = a->qo_len;
   kp.single_kv_len = a->kv_len;
   kp.causal = a->mask_mode == FI_MASK_CAUSAL;
+  if (a->mask_mode == FI_MASK_CUSTOM) kp.custom_mask = a->custom_mask;
   kp.window_left = a->window_left;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
   kp.o_dtype = a->o_dtype;

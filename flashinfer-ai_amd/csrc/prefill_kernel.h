@@ -48,6 +48,8 @@ struct PrefillKernelParams {
   const float* scale_q;  // fp8: per qo head / kv head scales (NULL = 1)
   const float* scale_k;
   const float* scale_v;
+  const uint8_t* custom_mask;    // packed bits (mask mode CUSTOM), NULL otherwise
+  const int32_t* mask_indptr;    // per-request byte offsets into custom_mask (NULL: 0)
   int64_t q_stride_n, q_stride_h;
   int64_t kv_stride_page, kv_stride_n, kv_stride_h;  // host checks stride_page / stride_n < 2^31
   int32_t num_work;
@@ -155,7 +157,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   using frag_t = typename M::frag;
   constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
   constexpr bool Q_FP8 = (QS == FI_DTYPE_FP8_E4M3 || QS == FI_DTYPE_FP8_E5M2);
-  constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
+  [[maybe_unused]] constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
   constexpr int ROWB = D * 2;             // bytes per row of the 16-bit LDS images
   constexpr int CPR = D / 8;              // 16-byte chunks per row
   constexpr int RPP = kPrefillThreads / CPR;  // rows staged per pass
@@ -278,6 +280,9 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   const float inv_qk_scale = 1.0f / qk_scale;
   const float inv_cap = soft_cap ? 1.0f / p.logits_soft_cap : 0.f;
   const float slope = p.use_alibi ? p.alibi_slopes[qo_head] : 0.f;
+  const uint8_t* const mask_bits =
+      (GENERAL && p.custom_mask) ? p.custom_mask + (p.mask_indptr ? p.mask_indptr[req] : 0) : nullptr;
+  const uint64_t mask_row = (uint64_t)qo_idx * (uint64_t)kv_len;
 
   // ---- kv range of this workgroup ----
   int kv_end = kv_len;
@@ -480,7 +485,12 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
             float lg = s_acc[kbk][r] * qk_scale;
             if (p.use_alibi) lg += slope * (float)(kv_idx - qo_idx);
             if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg * inv_cap);
-            s_acc[kbk][r] = lg * inv_qk_scale;
+            lg *= inv_qk_scale;
+            if (mask_bits) {  // ref: variants.cuh:80-86 -- bit qo_idx * kv_len + kv_idx of the request's mask
+              const uint64_t off = mask_row + (uint64_t)min(kv_idx, kv_len - 1);
+              lg = ((mask_bits[off >> 3] >> (off & 7)) & 1) ? lg : -INFINITY;
+            }
+            s_acc[kbk][r] = lg;
           }
       }
       if (need_mask) {

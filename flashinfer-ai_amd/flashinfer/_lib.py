@@ -114,6 +114,8 @@ class BatchPrefillParams(C.Structure):
         ("scale_q", C.c_void_p),
         ("scale_k", C.c_void_p),
         ("scale_v", C.c_void_p),
+        ("custom_mask", C.c_void_p),
+        ("mask_indptr", C.c_void_p),
         ("num_qo_heads", C.c_int32),
         ("q_dtype", C.c_int32),
         ("o_dtype", C.c_int32),
@@ -142,6 +144,7 @@ class SinglePrefillParams(C.Structure):
         ("scale_q", C.c_void_p),
         ("scale_k", C.c_void_p),
         ("scale_v", C.c_void_p),
+        ("custom_mask", C.c_void_p),
         ("qo_len", C.c_int32),
         ("kv_len", C.c_int32),
         ("num_qo_heads", C.c_int32),
@@ -197,6 +200,8 @@ EXPORTED_SYMBOLS = [
     "fi_append_paged_kv_cache",
     "fi_apply_rope_pos_ids",
     "fi_rope_positions_from_indptr",
+    "fi_packbits",
+    "fi_segment_packbits",
 ]
 
 
@@ -227,6 +232,8 @@ def lib() -> C.CDLL:
     l.fi_single_prefill_run.argtypes = [C.POINTER(SinglePrefillParams), vp, sz, vp]
     l.fi_gemm_fp8_nt_groupwise.argtypes = [vp] * 5 + [i32] * 10 + [vp]
     l.fi_group_gemm_fp8_nt_groupwise.argtypes = [vp] * 6 + [i32] * 11 + [vp]
+    l.fi_packbits.argtypes = [vp, C.c_int64, i32, vp, vp]
+    l.fi_segment_packbits.argtypes = [vp, vp, vp, i32, C.c_int64, i32, vp, vp]
     l.fi_get_batch_indices_positions.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     l.fi_append_paged_kv_cache.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp, i32, C.POINTER(PagedKV), vp]
     l.fi_apply_rope_pos_ids.argtypes = [C.POINTER(RopeParams), vp]

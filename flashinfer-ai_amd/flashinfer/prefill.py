@@ -16,6 +16,7 @@ import torch
 
 from . import _lib
 from .page import get_seq_lens
+from .quantization import packbits, segment_packbits
 from .utils import (
     MaskMode,
     PosEncodingMode,
@@ -44,6 +45,45 @@ def _scale_tensor(x, n: int, device) -> Optional[torch.Tensor]:
     if x.numel() != n:
         raise ValueError(f"scale tensor must have {n} entries, got {x.numel()}")
     return x
+
+
+def _plan_custom_mask(wrapper, custom_mask, packed_custom_mask, qo_indptr_host, kv_lens_host, non_blocking):
+    """(packed mask, byte indptr) on the wrapper's device, or (None, None).
+    ref: _compute_page_mask_indptr + segment_packbits, flashinfer/prefill.py:1203-1223, 1693-1706; in
+    CUDA-graph mode the caller-provided custom_mask_buf / mask_indptr_buf are filled (:1838-1857)."""
+    if custom_mask is None and packed_custom_mask is None:
+        return None, None
+    qo_lens = (qo_indptr_host[1:] - qo_indptr_host[:-1]).to(torch.int64)
+    bits = qo_lens * kv_lens_host.to(torch.int64)
+    bit_indptr = torch.zeros(len(qo_indptr_host), dtype=torch.int64)
+    bit_indptr[1:] = torch.cumsum(bits, 0)
+    if int(((bits + 7) // 8).sum()) >= 2 ** 31:
+        raise ValueError("custom mask too large: byte offsets must fit int32")
+    if packed_custom_mask is None:
+        custom_mask = custom_mask.to(wrapper.device).contiguous().view(-1)
+        if custom_mask.numel() != int(bit_indptr[-1]):
+            raise ValueError(
+                f"custom_mask has {custom_mask.numel()} entries, expected sum(qo_len * kv_len) = {int(bit_indptr[-1])}")
+        packed_custom_mask, mask_indptr = segment_packbits(
+            custom_mask, bit_indptr.to(torch.int32).to(wrapper.device), bitorder="little")
+    else:
+        mask_indptr = torch.zeros(len(qo_indptr_host), dtype=torch.int32)
+        mask_indptr[1:] = torch.cumsum((bits + 7) // 8, 0)
+        mask_indptr = mask_indptr.to(wrapper.device, non_blocking=non_blocking)
+        packed_custom_mask = packed_custom_mask.to(wrapper.device)
+        if packed_custom_mask.dtype != torch.uint8:
+            raise ValueError("packed_custom_mask must be uint8")
+    if wrapper.is_cuda_graph_enabled:
+        mask_buf = getattr(wrapper, "_user_custom_mask_buf", None)
+        indptr_buf = getattr(wrapper, "_user_mask_indptr_buf", None)
+        if mask_buf is None or indptr_buf is None:
+            raise ValueError("custom_mask_buf and mask_indptr_buf are required for custom masks in cuda graph mode")
+        if packed_custom_mask.numel() > mask_buf.numel():
+            raise ValueError("packed custom mask exceeds custom_mask_buf")
+        mask_buf[: packed_custom_mask.numel()].copy_(packed_custom_mask, non_blocking=non_blocking)
+        indptr_buf[: len(mask_indptr)].copy_(mask_indptr, non_blocking=non_blocking)
+        return mask_buf, indptr_buf
+    return packed_custom_mask.contiguous(), mask_indptr.contiguous()
 
 
 def single_prefill_with_kv_cache(
@@ -81,12 +121,15 @@ def single_prefill_with_kv_cache(
     sm_scale, window_left, logits_soft_cap, rope_scale, rope_theta : as the reference
     return_lse : also return the base-2 logsumexp, shape ``[qo_len, num_qo_heads]``
 
-    Custom masks are not implemented in this build (ValueError).  (ref: flashinfer/prefill.py:960-1194)
+    custom_mask : ``[qo_len, kv_len]`` bool; packed_custom_mask : its ``packbits(..., bitorder="little")``
+        form (takes precedence).  With a mask, ``causal`` is ignored (mask mode CUSTOM).
+    (ref: flashinfer/prefill.py:960-1194)
     """
     _check_pos_encoding_mode(pos_encoding_mode)
     _check_kv_layout(kv_layout)
-    if custom_mask is not None or packed_custom_mask is not None:
-        raise ValueError("custom masks are not supported by the MI355X backend yet")
+    if custom_mask is not None and packed_custom_mask is None:
+        # ref: prefill.py:1114-1118
+        packed_custom_mask = packbits(custom_mask.contiguous().view(-1), bitorder="little")
     for t, name in ((q, "q"), (k, "k"), (v, "v")):
         _lib.require_gpu_tensor(t, name)
     if q.dim() != 3 or k.dim() != 3 or k.shape != v.shape:
@@ -124,6 +167,11 @@ def single_prefill_with_kv_cache(
     lse = None
     if return_lse:
         lse = torch.empty((qo_len, num_qo_heads), dtype=torch.float32, device=q.device)
+    if packed_custom_mask is not None:
+        _lib.require_gpu_tensor(packed_custom_mask, "packed_custom_mask")
+        if packed_custom_mask.dtype != torch.uint8 or packed_custom_mask.numel() * 8 < qo_len * kv_len:
+            raise ValueError("packed_custom_mask must be uint8 with at least qo_len * kv_len bits")
+        packed_custom_mask = packed_custom_mask.contiguous()
     alibi = _get_cache_alibi_slopes_buf(num_qo_heads, q.device) if pos_encoding_mode == "ALIBI" else None
     params = _lib.SinglePrefillParams(
         q=q.data_ptr(), q_stride_n=q.stride(0), q_stride_h=q.stride(1), k=k.data_ptr(), v=v.data_ptr(),
@@ -132,7 +180,9 @@ def single_prefill_with_kv_cache(
         scale_v=_lib.ptr(scale_v), qo_len=qo_len, kv_len=kv_len, num_qo_heads=num_qo_heads,
         num_kv_heads=num_kv_heads, head_dim=head_dim, q_dtype=_lib.fi_dtype(q.dtype),
         kv_dtype=_lib.fi_dtype(k.dtype), o_dtype=_lib.fi_dtype(o_dtype),
-        mask_mode=MaskMode.CAUSAL.value if causal else MaskMode.NON_CAUSAL.value,
+        custom_mask=_lib.ptr(packed_custom_mask),
+        mask_mode=(MaskMode.CUSTOM.value if packed_custom_mask is not None
+                   else MaskMode.CAUSAL.value if causal else MaskMode.NON_CAUSAL.value),
         pos_encoding_mode=PosEncodingMode[pos_encoding_mode].value, window_left=window_left,
         logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
         rope_rcp_theta=1.0 / rope_theta,
@@ -207,6 +257,9 @@ class BatchPrefillWithPagedKVCacheWrapper:
         self._paged_kv_indptr_buf = paged_kv_indptr_buf
         self._paged_kv_indices_buf = paged_kv_indices_buf
         self._paged_kv_last_page_len_buf = paged_kv_last_page_len_buf
+        self._user_custom_mask_buf = custom_mask_buf
+        self._user_mask_indptr_buf = mask_indptr_buf
+        self._custom_mask_buf = self._mask_indptr_buf = None
         self._backend = backend
         self._plan_info = None
 
@@ -267,11 +320,12 @@ class BatchPrefillWithPagedKVCacheWrapper:
         causal, pos_encoding_mode, sm_scale, window_left, logits_soft_cap, rope_* configure the variant.
         q_data_type / kv_data_type : dtypes the run() tensors will have (fp8 e4m3 for both = fp8 attention).
         o_data_type : (extension) output dtype; defaults to the q dtype, or bfloat16 for fp8 queries.
-        Custom masks and multi-item scoring are not implemented (ValueError).
+        custom_mask : flattened bool mask, request i contributes ``qo_len[i] * kv_len[i]`` entries
+            (row-major ``[qo_len, kv_len]``); packed_custom_mask : its ``segment_packbits(..., "little")`` form.
+            With a mask the mask mode is CUSTOM and ``causal`` is ignored (ref: prefill.py:1693-1706, 1890-1905).
+        Multi-item scoring is not implemented (ValueError).
         (ref: flashinfer/prefill.py:1523-1921)
         """
-        if custom_mask is not None or packed_custom_mask is not None:
-            raise ValueError("custom masks are not supported by the MI355X backend yet")
         if prefix_len_ptr is not None or token_pos_in_items_ptr is not None or max_item_len_ptr is not None:
             raise ValueError("multi-item scoring is not supported by the MI355X backend")
         for tensor, name in [(qo_indptr, "qo_indptr"), (paged_kv_indptr, "paged_kv_indptr"),
@@ -304,6 +358,10 @@ class BatchPrefillWithPagedKVCacheWrapper:
             kv_lens_arr_host = seq_lens.cpu()
         kv_lens_arr_host = kv_lens_arr_host.to(torch.int32).contiguous()
         total_num_rows = int(qo_indptr_host[-1])
+        self._custom_mask_buf, self._mask_indptr_buf = _plan_custom_mask(
+            self, custom_mask, packed_custom_mask, qo_indptr_host, kv_lens_arr_host, non_blocking)
+        if self._custom_mask_buf is not None:
+            causal = False  # mask mode CUSTOM: every kv tile is visited, the bits decide
 
         if self.is_cuda_graph_enabled:
             if batch_size != self._fixed_batch_size:
@@ -488,7 +546,9 @@ class BatchPrefillWithPagedKVCacheWrapper:
             o=out.data_ptr(), lse=_lib.ptr(lse) if return_lse else None, alibi_slopes=_lib.ptr(alibi),
             scale_q=_lib.ptr(scale_q), scale_k=_lib.ptr(scale_k), scale_v=_lib.ptr(scale_v),
             num_qo_heads=self._num_qo_heads, q_dtype=_lib.fi_dtype(q.dtype), o_dtype=_lib.fi_dtype(o_dtype),
-            mask_mode=MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value,
+            custom_mask=_lib.ptr(self._custom_mask_buf), mask_indptr=_lib.ptr(self._mask_indptr_buf),
+            mask_mode=(MaskMode.CUSTOM.value if self._custom_mask_buf is not None
+                       else MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value),
             pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=window_left,
             logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
             rope_rcp_theta=1.0 / rope_theta,
@@ -576,6 +636,9 @@ class BatchPrefillWithRaggedKVCacheWrapper:
             self._fixed_batch_size = 0
         self._qo_indptr_buf = qo_indptr_buf
         self._kv_indptr_buf = kv_indptr_buf
+        self._user_custom_mask_buf = custom_mask_buf
+        self._user_mask_indptr_buf = mask_indptr_buf
+        self._custom_mask_buf = self._mask_indptr_buf = None
         self._plan_info = None
 
     @property
@@ -619,8 +682,6 @@ class BatchPrefillWithRaggedKVCacheWrapper:
     ) -> None:
         r"""Plan for ragged queries ``qo_indptr`` and ragged keys/values ``kv_indptr`` (both int32
         ``[batch_size + 1]``).  Options as :meth:`BatchPrefillWithPagedKVCacheWrapper.plan`."""
-        if custom_mask is not None or packed_custom_mask is not None:
-            raise ValueError("custom masks are not supported by the MI355X backend yet")
         if prefix_len_ptr is not None or token_pos_in_items_ptr is not None or max_item_len_ptr is not None:
             raise ValueError("multi-item scoring is not supported by the MI355X backend")
         for tensor, name in [(qo_indptr, "qo_indptr"), (kv_indptr, "kv_indptr")]:
@@ -642,6 +703,10 @@ class BatchPrefillWithRaggedKVCacheWrapper:
         kv_indptr_host = kv_indptr.to("cpu").contiguous()
         kv_len_arr = (kv_indptr_host[1:] - kv_indptr_host[:-1]).to(torch.int32).contiguous()
         total_num_rows = int(qo_indptr_host[-1])
+        self._custom_mask_buf, self._mask_indptr_buf = _plan_custom_mask(
+            self, custom_mask, packed_custom_mask, qo_indptr_host, kv_len_arr, non_blocking)
+        if self._custom_mask_buf is not None:
+            causal = False
         if self.is_cuda_graph_enabled:
             if batch_size != self._fixed_batch_size:
                 raise ValueError("The batch size should be fixed in cuda graph mode")
@@ -751,8 +816,10 @@ class BatchPrefillWithRaggedKVCacheWrapper:
             ),
             o=out.data_ptr(), lse=_lib.ptr(lse) if return_lse else None, alibi_slopes=_lib.ptr(alibi),
             scale_q=None, scale_k=None, scale_v=None, num_qo_heads=self._num_qo_heads,
+            custom_mask=_lib.ptr(self._custom_mask_buf), mask_indptr=_lib.ptr(self._mask_indptr_buf),
             q_dtype=_lib.fi_dtype(q.dtype), o_dtype=_lib.fi_dtype(q.dtype),
-            mask_mode=MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value,
+            mask_mode=(MaskMode.CUSTOM.value if self._custom_mask_buf is not None
+                       else MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value),
             pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=self._window_left,
             logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
             rope_rcp_theta=1.0 / rope_theta,

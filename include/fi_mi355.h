@@ -237,10 +237,15 @@ typedef struct fi_batch_prefill_params {
   const float* scale_q; /* fp8 path: [num_qo_heads] (NULL = 1) */
   const float* scale_k; /* [num_kv_heads] */
   const float* scale_v; /* [num_kv_heads] */
+  /* mask_mode CUSTOM (ref variants.cuh:57-86): bit (qo_idx * kv_len + kv_idx) of request r, little-endian
+   * within bytes, starting at byte mask_indptr[r] of custom_mask (flashinfer.quantization.segment_packbits
+   * layout, ref prefill.py:1203-1223, 1693-1706) */
+  const uint8_t* custom_mask;
+  const int32_t* mask_indptr; /* [batch+1] device, byte offsets */
   int32_t num_qo_heads;
   int32_t q_dtype; /* f16 / bf16 / fp8_e4m3 (then kv must be fp8_e4m3 too) */
   int32_t o_dtype; /* f16 / bf16 */
-  int32_t mask_mode; /* fi_mask_mode: NON_CAUSAL / CAUSAL */
+  int32_t mask_mode; /* fi_mask_mode: NON_CAUSAL / CAUSAL / CUSTOM */
   int32_t pos_encoding_mode;
   int32_t window_left;
   float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
@@ -266,6 +271,7 @@ typedef struct fi_single_prefill_params {
   const float* scale_q;
   const float* scale_k;
   const float* scale_v;
+  const uint8_t* custom_mask; /* mask_mode CUSTOM: packed [qo_len * kv_len] bits, little-endian */
   int32_t qo_len, kv_len, num_qo_heads, num_kv_heads, head_dim;
   int32_t q_dtype, kv_dtype, o_dtype;
   int32_t mask_mode, pos_encoding_mode, window_left;
@@ -274,6 +280,17 @@ typedef struct fi_single_prefill_params {
 
 FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* params, void* tmp, size_t tmp_bytes,
                           fi_stream_t stream);
+
+/* Bit packing of boolean masks (numpy.packbits semantics).  ref: csrc/quantization.cu,
+ * include/flashinfer/quantization.cuh:29-126, Python flashinfer/quantization.py:57-153.
+ *   x: n bytes, each 0 / non-zero;  y: ceil(n / 8) bytes;  bitorder_little: 0 = "big", 1 = "little".
+ * Segment form: segment i is x[in_indptr[i] : in_indptr[i+1]], packed into
+ * y[out_indptr[i] : out_indptr[i+1]] with out_indptr[i+1] - out_indptr[i] = ceil(len_i / 8) (both int32
+ * device arrays of batch + 1 entries; y_bytes = out_indptr[batch], passed by the host for the launch). */
+FI_API int fi_packbits(const uint8_t* x, int64_t n, int32_t bitorder_little, uint8_t* y, fi_stream_t stream);
+FI_API int fi_segment_packbits(const uint8_t* x, const int32_t* in_indptr, const int32_t* out_indptr,
+                               int32_t batch, int64_t y_bytes, int32_t bitorder_little, uint8_t* y,
+                               fi_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * fp8 groupwise-scaled GEMM / grouped GEMM ("nt": D = A . B^T, B given as (n, k)).

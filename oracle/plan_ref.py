@@ -26,6 +26,16 @@ def pick_head_tile(group_size: int, kv_bytes: int = 2) -> int:
     return 4
 
 
+def head_tiles(group_size: int, kv_bytes: int = 2, head_dim: int = 128) -> int:
+    """Work items per (request chunk, kv head).  Groups of 5..32 heads (3..32 with an fp8 cache) at
+    head_dim 64/128 run on the matrix-core decode kernel, where one wave covers the whole group; smaller
+    groups use the VALU kernel's q-head tiles of <= 4 heads (flashinfer-ai_amd/csrc/decode.hip)."""
+    min_group = 3 if kv_bytes == 1 else 5
+    if min_group <= group_size <= 32 and head_dim in (64, 128):
+        return 1
+    return ceil_div(group_size, pick_head_tile(group_size, kv_bytes))
+
+
 def partition_pages(max_grid: int, gdy: int, num_pages: List[int], min_pages: int) -> Tuple[int, int]:
     low, high = min_pages, max(num_pages + [0])
     while low < high:
@@ -39,10 +49,10 @@ def partition_pages(max_grid: int, gdy: int, num_pages: List[int], min_pages: in
 
 
 def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, page_size: int,
-                    max_grid: int, enable_cuda_graph: bool = False, kv_bytes: int = 2):
+                    max_grid: int, enable_cuda_graph: bool = False, kv_bytes: int = 2, head_dim: int = 128):
     batch = len(indptr) - 1
     group = num_qo_heads // num_kv_heads
-    gdy = num_kv_heads * ceil_div(group, pick_head_tile(group, kv_bytes))
+    gdy = num_kv_heads * head_tiles(group, kv_bytes, head_dim)
     num_pages = [indptr[i + 1] - indptr[i] for i in range(batch)]
     if batch * gdy >= max_grid:
         split, chunk_pages, new_batch = False, max(num_pages + [1]), batch

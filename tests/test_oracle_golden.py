@@ -130,3 +130,21 @@ def test_sliding_window_and_soft_cap_definitions():
     # soft cap -> logits bounded by the cap
     o_c, lse_c = R.attention_ref(q * 50, k, v, logits_soft_cap=1.0)
     assert (lse_c <= (1.0 + np.log(20)) * R.LOG2E + 1e-9).all()
+
+
+def test_packbits_oracle_on_reference_docstring_vectors():
+    """flashinfer/quantization.py:79-82, 121-127 (the reference's own worked examples)."""
+    x = torch.tensor([1, 0, 1, 1, 0, 0, 1, 1], dtype=torch.bool)
+    assert R.packbits_ref(x).tolist() == [0b10110011]
+    x = torch.tensor([1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 1], dtype=torch.bool)
+    y, ind = R.segment_packbits_ref(x, torch.tensor([0, 4, 7, 11]), "big")
+    assert y.tolist() == [0b10110000, 0b00100000, 0b11010000] and ind.tolist() == [0, 1, 2, 3]
+
+
+def test_custom_mask_oracle_equals_causal_oracle():
+    torch.manual_seed(0)
+    q, k, v = torch.randn(9, 4, 16), torch.randn(20, 2, 16), torch.randn(20, 2, 16)
+    m = torch.tril(torch.ones(9, 20, dtype=torch.bool), diagonal=11)
+    o1, l1 = R.attention_ref(q, k, v, causal=True)
+    o2, l2 = R.attention_ref(q, k, v, custom_mask=m)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2)
