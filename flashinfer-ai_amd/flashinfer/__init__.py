@@ -23,6 +23,7 @@ from .decode import (
 from .decode import (
     CUDAGraphBatchDecodeWithPagedKVCacheWrapper as CUDAGraphBatchDecodeWithPagedKVCacheWrapper,
 )
+from .decode import fast_decode_plan as fast_decode_plan
 from .decode import single_decode_with_kv_cache as single_decode_with_kv_cache
 from .gemm import gemm_fp8_nt_groupwise as gemm_fp8_nt_groupwise
 from .gemm import group_gemm_fp8_nt_groupwise as group_gemm_fp8_nt_groupwise

@@ -33,6 +33,46 @@ from .utils import (
 )
 
 
+def fast_decode_plan(
+    self: "BatchDecodeWithPagedKVCacheWrapper",
+    indptr: torch.Tensor,
+    indices: torch.Tensor,
+    last_page_len: torch.Tensor,
+    num_qo_heads: int,
+    num_kv_heads: int,
+    head_dim: int,
+    page_size: int,
+    pos_encoding_mode: str = "NONE",
+    window_left: int = -1,
+    logits_soft_cap: Optional[float] = None,
+    q_data_type: Optional[Union[str, torch.dtype]] = None,
+    kv_data_type: Optional[Union[str, torch.dtype]] = None,
+    data_type: Optional[Union[str, torch.dtype]] = None,
+    sm_scale: Optional[float] = None,
+    rope_scale: Optional[float] = None,
+    rope_theta: Optional[float] = None,
+    non_blocking: bool = True,
+    fixed_split_size: Optional[int] = None,
+    disable_split_kv: bool = False,
+    global_override_indptr_cpu: Optional[torch.Tensor] = None,
+) -> None:
+    """A faster :meth:`BatchDecodeWithPagedKVCacheWrapper.plan` for multi-step draft decoding
+    (ref: flashinfer/decode.py:2416-2579): the device-to-device copies into the graph buffers are skipped
+    (the caller wrote them in place; outside graph mode the given tensors are adopted without a copy), and
+    ``global_override_indptr_cpu`` supplies the host page-table prefix sums so that no device-to-host copy
+    is needed.  Bind it with ``wrapper.begin_forward = functools.partial(fast_decode_plan, wrapper)``."""
+    if data_type is None and q_data_type is None:
+        q_data_type = "float16"
+    self.plan(
+        indptr, indices, last_page_len, num_qo_heads, num_kv_heads, head_dim, page_size,
+        pos_encoding_mode=pos_encoding_mode, window_left=window_left, logits_soft_cap=logits_soft_cap,
+        q_data_type=q_data_type, kv_data_type=kv_data_type, data_type=data_type, sm_scale=sm_scale,
+        rope_scale=rope_scale, rope_theta=rope_theta, non_blocking=non_blocking,
+        fixed_split_size=None,  # as the reference: not forwarded by the fast path
+        disable_split_kv=disable_split_kv, _fast=True, _indptr_host=global_override_indptr_cpu,
+    )
+
+
 def single_decode_with_kv_cache(
     q: torch.Tensor,
     k: torch.Tensor,
@@ -263,6 +303,8 @@ class BatchDecodeWithPagedKVCacheWrapper:
         seq_lens: Optional[torch.Tensor] = None,
         fixed_split_size: Optional[int] = None,
         disable_split_kv: bool = False,
+        _fast: bool = False,
+        _indptr_host: Optional[torch.Tensor] = None,
     ) -> None:
         r"""Plan batch decode for the given page table (ref: flashinfer/decode.py:810-1104).
 
@@ -290,16 +332,23 @@ class BatchDecodeWithPagedKVCacheWrapper:
                 raise ValueError(
                     "The size of indices should be less than or equal to the allocated buffer"
                 )
-            self._paged_kv_indptr_buf.copy_(indptr, non_blocking=non_blocking)
-            self._paged_kv_last_page_len_buf.copy_(last_page_len, non_blocking=non_blocking)
-            self._paged_kv_indices_buf[: len(indices)].copy_(
-                indices, non_blocking=(indices.device == self.device) and non_blocking
-            )
+            if not _fast:  # fast_decode_plan: the caller already wrote the graph buffers in place
+                self._paged_kv_indptr_buf.copy_(indptr, non_blocking=non_blocking)
+                self._paged_kv_last_page_len_buf.copy_(last_page_len, non_blocking=non_blocking)
+                self._paged_kv_indices_buf[: len(indices)].copy_(
+                    indices, non_blocking=(indices.device == self.device) and non_blocking
+                )
+        elif _fast:
+            self._paged_kv_indptr_buf = indptr
+            self._paged_kv_indices_buf = indices
+            self._paged_kv_last_page_len_buf = last_page_len
         else:
             self._paged_kv_indptr_buf = indptr.to(self.device, non_blocking=non_blocking)
             self._paged_kv_indices_buf = indices.to(self.device, non_blocking=non_blocking)
             self._paged_kv_last_page_len_buf = last_page_len.to(self.device, non_blocking=non_blocking)
-        indptr_host = indptr.to("cpu").contiguous()
+        indptr_host = (indptr if _indptr_host is None else _indptr_host).to("cpu").contiguous()
+        if indptr_host.dtype != torch.int32 or len(indptr_host) != batch_size + 1:
+            raise ValueError("indptr must be int32 with batch_size + 1 entries")
 
         if data_type is not None:
             if q_data_type is None:
@@ -320,7 +369,9 @@ class BatchDecodeWithPagedKVCacheWrapper:
         self._num_kv_heads = num_kv_heads
         self._head_dim = head_dim
         self._page_size = page_size
-        if seq_lens is None:
+        if _fast:
+            self._kv_lens_host = None  # not needed by run(); skipping it saves a device-to-host copy
+        elif seq_lens is None:
             last_page_len_host = last_page_len.to("cpu")
             self._kv_lens_host = get_seq_lens(indptr_host, last_page_len_host, page_size)
         else:

@@ -317,3 +317,36 @@ def test_run_is_graph_capturable():
     torch.cuda.synchronize()
     o_ref, _ = R.batch_decode_ref(q.float().cpu(), cache.float(), "NHD", indptr, indices, last)
     torch.testing.assert_close(out.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_fast_decode_plan_matches_plan():
+    """ref: flashinfer/decode.py:2416-2579 -- same plan, no buffer copies, host indptr supplied by the caller."""
+    import functools
+
+    import flashinfer
+
+    hq, hkv, d, page_size = 32, 8, 128, 16
+    kv_lens = [100, 2000, 17, 512]
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, page_size, hkv, d, torch.float16, "NHD", seed=8)
+    torch.manual_seed(9)
+    q = torch.randn(len(kv_lens), hq, d).half().to(DEV)
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchDecodeWithPagedKVCacheWrapper(ws, "NHD")
+    w.plan(indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, page_size, q_data_type=torch.float16)
+    o_ref = w.run(q, cache.to(DEV))
+    # graph-mode wrapper whose buffers the caller fills in place
+    bufs = (torch.zeros(len(kv_lens) + 1, dtype=torch.int32, device=DEV),
+            torch.zeros(len(indices) + 8, dtype=torch.int32, device=DEV),
+            torch.zeros(len(kv_lens), dtype=torch.int32, device=DEV))
+    wg = flashinfer.BatchDecodeWithPagedKVCacheWrapper(ws, "NHD", use_cuda_graph=True, paged_kv_indptr_buffer=bufs[0],
+                                                       paged_kv_indices_buffer=bufs[1], paged_kv_last_page_len_buffer=bufs[2])
+    wg.begin_forward = functools.partial(flashinfer.fast_decode_plan, wg)
+    bufs[0].copy_(indptr)
+    bufs[1][: len(indices)].copy_(indices)
+    bufs[2].copy_(last)
+    wg.begin_forward(bufs[0], bufs[1][: len(indices)], bufs[2], hq, hkv, d, page_size, q_data_type=torch.float16,
+                     global_override_indptr_cpu=indptr)
+    o = wg.run(q, cache.to(DEV))
+    assert torch.equal(o, o_ref) or torch.allclose(o.float(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    o_ora, _ = R.batch_decode_ref(q.float().cpu(), cache.float(), "NHD", indptr, indices, last)
+    torch.testing.assert_close(o.float().cpu(), o_ora.float(), rtol=1e-3, atol=1e-3)
