@@ -31,6 +31,7 @@ constexpr int kPrefillThreads = 256;
 constexpr int kPrefillWaves = 4;
 constexpr int kTileQ = 128;   // packed query rows per workgroup
 constexpr int kTileKV = 64;   // kv rows per LDS tile
+constexpr int kQkPrefetch = 4;  // K fragments in flight ahead of the QK^T MFMA chain
 
 struct PrefillKernelParams {
   const void* q;
@@ -170,6 +171,9 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [stage][K tile | V tile]
   char* const lds_base = smem;
+  // byte offset of every kv row of a tile inside the cache (page gather resolved once per workgroup by
+  // one wave, three tiles ahead); slot = tile index mod 4
+  __shared__ uint64_t row_off_tab[4][kTileKV];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -306,17 +310,25 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   const int st_ch = tid % CPR;   // 16-byte chunk (8 elements) within the row
   const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
 
-  const int64_t thread_off = head_off + st_ch * 8;  // element offset of this thread inside a kv row
+  // this thread's chunk inside a kv row, folded into per-thread K / V base pointers
+  const char* const k_thr = (const char*)p.k + (head_off + st_ch * 8) * KV_BYTES;
+  const char* const v_thr = (const char*)p.v + (head_off + st_ch * 8) * KV_BYTES;
   const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
-  // page id and in-page entry of the rows this thread stages, fetched two tiles ahead
-  auto fetch_pages = [&](int tile, int (&pg)[NPASS], int (&en)[NPASS]) {
+  // (page id, in-page entry) of kv row `lane` of a tile: evaluated by ONE wave per tile
+  auto tab_lookup = [&](int tile, int& pg, int& en) {
+    const int kvi = max(min(tile * kTileKV + lane, kv_len - 1), 0);
+    const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+    en = kvi - pi * p.page_size;
+    pg = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
+  };
+  auto tab_store = [&](int slot, int pg, int en) {
+    // 32 x 32 -> 64-bit multiply-adds (strides fit in 31 bits, checked on the host)
+    row_off_tab[slot][lane] =
+        ((uint64_t)(uint32_t)pg * stride_page32 + (uint64_t)(uint32_t)en * stride_n32) * KV_BYTES;
+  };
+  auto read_offsets = [&](int slot, uint64_t (&roff)[NPASS]) {
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int kvi = max(min(tile * kTileKV + ps * RPP + st_row, kv_len - 1), 0);
-      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
-      en[ps] = kvi - pi * p.page_size;
-      pg[ps] = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
-    }
+    for (int ps = 0; ps < NPASS; ++ps) roff[ps] = row_off_tab[slot][ps * RPP + st_row];
   };
   // One register set stages K and then V of the next tile (K is written to LDS -- the OTHER buffer, free
   // since the last barrier -- as soon as QK^T of the current tile has been issued, then the same registers
@@ -324,17 +336,14 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   struct Stage {
     u32x4 r[NPASS];
   };
-  auto issue_loads = [&](const void* base, const int (&pg)[NPASS], const int (&en)[NPASS], Stage& st) {
+  auto issue_loads = [&](const char* base_thr, const uint64_t (&roff)[NPASS], Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      // 32 x 32 -> 64-bit multiply-adds (strides fit in 31 bits, checked on the host)
-      const int64_t off = (int64_t)((uint64_t)(uint32_t)pg[ps] * stride_page32 +
-                                    (uint64_t)(uint32_t)en[ps] * stride_n32) + thread_off;
       if constexpr (KV_FP8) {
-        const u32x2 rk = *(const u32x2*)((const uint8_t*)base + off);
+        const u32x2 rk = *(const u32x2*)(base_thr + roff[ps]);
         st.r[ps] = u32x4{rk[0], rk[1], 0, 0};
       } else {
-        st.r[ps] = *(const u32x4*)((const uint16_t*)base + off);
+        st.r[ps] = *(const u32x4*)(base_thr + roff[ps]);
       }
     }
   };
@@ -421,52 +430,78 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   float m_run = -1.0e30f, l_run = 0.f;
 
   if (num_tiles > 0) {
-    // pg/en: page ids + entries of the tile being staged (tile t+1 while t is consumed); pgn/enn: the
-    // ids of tile t+2, fetched as soon as the K/V loads of t+1 have been issued.
-    int pg[NPASS], en[NPASS], pgn[NPASS], enn[NPASS];
-    Stage st;
-    fetch_pages(0, pg, en);
-    issue_loads(p.k, pg, en, st);
-    write_k(0, 0, st);
-    issue_loads(p.v, pg, en, st);
-    fetch_pages(1, pgn, enn);
-    write_v(0, st);
+    // K rows are loaded TWO tiles ahead (during tile t the K rows of tile t+2 are in flight into kst; a tile
+    // period is about one HBM round trip under load, the QK^T phase alone is not), V rows one tile ahead
+    // (issued after QK^T, written to LDS before the closing barrier).  The row-offset table of tile t+3 is
+    // produced during tile t by wave t % 4.
+    uint64_t roff[NPASS];
+    Stage kst, vst;
+    if (wave < 3) {
+      int pg0, en0;
+      tab_lookup(min(wave, num_tiles - 1), pg0, en0);
+      tab_store(wave, pg0, en0);
+    }
+    __syncthreads();
+    read_offsets(0, roff);
+    issue_loads(k_thr, roff, kst);
+    issue_loads(v_thr, roff, vst);
+    write_k(0, 0, kst);
+    write_v(0, vst);
+    read_offsets(1, roff);
+    issue_loads(k_thr, roff, kst);
     __syncthreads();
     // The tile body is instantiated for the even and the odd LDS buffer so that every LDS address is a
-    // lane-constant register plus an immediate.
+    // lane-constant register plus an immediate.  Tiles past the end are clamped to the last one (re-staged
+    // into the idle buffer): no branch around a load, so the compiler's vmcnt counts stay exact.
     auto tile_body = [&](auto buf_c, const int t) {
       constexpr int buf = decltype(buf_c)::value;
-      const bool has_next = t + 1 < num_tiles;
-      if (has_next) {
-#pragma unroll
-        for (int ps = 0; ps < NPASS; ++ps) {
-          pg[ps] = pgn[ps];
-          en[ps] = enn[ps];
-        }
-        issue_loads(p.k, pg, en, st);
-      }
+      const int t_next = min(t + 1, num_tiles - 1);
+      write_k(t_next, buf ^ 1, kst);     // K rows of tile t+1 (loaded during tile t-1)
+      read_offsets((t + 2) & 3, roff);
+      issue_loads(k_thr, roff, kst);     // K rows of tile t+2
+      const bool tab_wave = wave == (t & 3);
+      int tab_pg = 0, tab_en = 0;
+      if (tab_wave) tab_lookup(min(t + 3, num_tiles - 1), tab_pg, tab_en);
       const char* kb = lds_base + buf * 2 * TILE_BYTES;
       const char* vb = kb + TILE_BYTES;
       const int tile0 = t * kTileKV;
 
       // ---- S^T = K Q^T ----
+      // The 2 x KSTEPS K fragments are read kQkPrefetch MFMAs ahead of their use (the LDS round trip is 2-4
+      // MFMA slots); sched_group_barrier pins that order, which the scheduler otherwise collapses into
+      // read -> wait -> MFMA pairs.
       f32x16 s_acc[2];
 #pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
+      for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
+      {
+        constexpr int NK = 2 * KSTEPS;
+        constexpr int PF = kQkPrefetch;
+        u32x4 kf[NK];
+        auto rd = [&](int i) {
+          return *(const u32x4*)(kb + (i / KSTEPS) * 32 * ROWB + k_rd[i % KSTEPS]);
+        };
 #pragma unroll
-        for (int ks = 0; ks < KSTEPS; ++ks) {
-          const u32x4 a = *(const u32x4*)(kb + kbk * 32 * ROWB + k_rd[ks]);
-          s_acc[kbk] = M::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc[kbk]);
+        for (int i = 0; i < PF; ++i) kf[i] = rd(i);
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          if (i + PF < NK) kf[i + PF] = rd(i + PF);
+          s_acc[i / KSTEPS] = M::mfma(__builtin_bit_cast(frag_t, kf[i]), qf[i % KSTEPS], s_acc[i / KSTEPS]);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int i = 0; i < NK - PF; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
       }
+      // nothing of the staging below (it waits for the K loads issued at the top) may move up into QK^T
+      __builtin_amdgcn_sched_barrier(0);
 
-      if (has_next) {
-        write_k(t + 1, buf ^ 1, st);
-        issue_loads(p.v, pg, en, st);
-        fetch_pages(t + 2, pgn, enn);
-      }
+      read_offsets((t + 1) & 3, roff);
+      issue_loads(v_thr, roff, vst);     // V rows of tile t+1
 
       // ---- logits transform + mask (ref: variants.cuh:67-91, prefill.cuh:782-786) ----
       // x holds c*logit (base-2 units) for the general path, or the RAW dot product on the plain path
@@ -513,24 +548,30 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kbk][r]);
       mx = fmaxf(mx, swap_halves(mx));
-      const float m_new = fmaxf(m_run, mx * c_log2);  // c_log2 > 0
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_new));
-          psum += s_acc[kbk][r];
-        }
-      l_run = l_run * alpha + psum;
-      if (__any(alpha != 1.0f)) {
+      // Deferred rescale: the reference exponent m_run only moves when some row of the wave outgrew it by
+      // more than kRescaleLog2 (then every row jumps to its true maximum); until then P is formed against
+      // the stale m_run and may reach 2^kRescaleLog2 -- exact power-of-two scaling, cancelled by l_run.
+      // Not used when P is rounded to e4m3 (fp8 q): that needs P <= 1.
+      constexpr float kRescaleLog2 = Q_FP8 ? 0.f : 6.f;
+      const float m_true = fmaxf(m_run, mx * c_log2);  // c_log2 > 0
+      if (__any(m_true - m_run > kRescaleLog2)) {
+        const float alpha = fast_exp2(m_run - m_true);
+        m_run = m_true;
+        l_run *= alpha;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
       }
+      float psum = 0.f;
+#pragma unroll
+      for (int kbk = 0; kbk < 2; ++kbk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_run));
+          psum += s_acc[kbk][r];
+        }
+      l_run += psum;
 
       // ---- O^T += V^T P^T ----
       // P^T fragments: accumulator registers 8s..8s+7 of block kb, rounded to 16 bit, are the B operand of
@@ -566,7 +607,8 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
         }
       }
 
-      if (has_next) write_v(buf ^ 1, st);
+      write_v(buf ^ 1, vst);
+      if (tab_wave) tab_store((t + 3) & 3, tab_pg, tab_en);
       __syncthreads();
     };
     int t = 0;

@@ -21,8 +21,8 @@ def run(dtype, b=16, qo=2048, kv=8192, hq=32, hkv=8, d=128, ps=16, causal=True, 
     ws = torch.zeros(128 << 20, dtype=torch.uint8, device=DEV)
     w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, "NHD")
     w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, causal=causal, q_data_type=dtype, kv_data_type=dtype,
-           o_data_type=torch.bfloat16)
-    out = torch.empty(b * qo, hq, d, device=DEV, dtype=torch.bfloat16)
+           o_data_type=torch.bfloat16 if dtype != torch.float16 else torch.float16)
+    out = torch.empty(b * qo, hq, d, device=DEV, dtype=torch.bfloat16 if dtype != torch.float16 else torch.float16)
     med, mn = bench(lambda: w.run(q, cache, out=out), iters=10, warm=3)
     flops = b * (2 * kv - qo) * qo * hq * 2 * d if causal else 2 * b * qo * kv * hq * 2 * d
     print(f"{tag:28s} {str(dtype):22s} causal={int(causal)} med={med:8.3f} ms min={mn:8.3f} ms  {flops/med/1e9:8.1f} TFLOP/s", flush=True)
