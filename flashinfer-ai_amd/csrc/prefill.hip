@@ -25,8 +25,8 @@ FI_PF_DECL_D(0, 2, 2) FI_PF_DECL_D(1, 2, 2)
 
 hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, hipStream_t stream);
 
-// fp8-native kernel (MX-scaled MFMA for both contractions): e4m3 q/k/v, head_dim 128, pages of a multiple
-// of 4 tokens, plain logits, no fused RoPE, no sliding window.  FI_PREFILL_FP8_NATIVE=0 forces the
+// fp8-native kernel (MX-scaled MFMA for both contractions): e4m3 q/k/v, head_dim 128, plain logits, no fused
+// RoPE, no sliding window.  FI_PREFILL_FP8_NATIVE=0 forces the
 // upcast-to-16-bit kernel (same arithmetic, kept as the cross-check).
 static bool use_fp8_native(const PrefillKernelParams& kp, int q_dt, int kv_dt, int head_dim, int rope) {
   static const bool enabled = [] {
@@ -34,7 +34,7 @@ static bool use_fp8_native(const PrefillKernelParams& kp, int q_dt, int kv_dt, i
     return e ? atoi(e) != 0 : true;
   }();
   return enabled && q_dt == FI_DTYPE_FP8_E4M3 && kv_dt == FI_DTYPE_FP8_E4M3 && head_dim == 128 &&
-         kp.page_size % 4 == 0 && !rope && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
+         !rope && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
          kp.window_left < 0 && !kp.custom_mask;
 }
 

@@ -10,12 +10,14 @@
 //   * P is quantised to e4m3 (x448) in registers exactly as the reference does
 //     (hopper/variants.cuh:72, 84-90) and used directly as the B operand: lane (q, h) holds the 32
 //     probabilities kv = 32 kb + 8 g + 4 h + e  (kb<2, g<4, e<4) in accumulator order.
-//   * V has to be the A operand with that same k order along each head_dim row, so the V tile is stored
-//     TRANSPOSED in LDS: image [128 d][64 B] with byte (h*32 + kb*16 + 4 g + e) of row d = V[kv][d].  The
-//     transpose is done when the tile is staged: a thread loads 4 kv rows x 4 d bytes, transposes the 4x4
-//     byte block with v_perm_b32 and writes four dwords.
-//   * the fp8 K image is [64 kv][128 B]; both images are XOR-swizzled on 16-byte slots so that every
-//     ds_read_b128 is conflict-free.
+//   * V has to be the A operand with that same k order along each head_dim row.  The V tile stays
+//     ROW-MAJOR in LDS ([64 kv][128 B], staged exactly like K with 16-byte loads and ds_write_b128) and is
+//     transposed on the way out by ds_read_b64_tr_b8: in a 16-lane group, lanes 2b and 2b+1 address the
+//     16 bytes of "row b" (any row), and lane j receives byte j of rows 0..7 -- so each lane gathers, per
+//     read, the 8 kv rows of its k order for its own head_dim column.
+//   * both images are XOR-swizzled on 16-byte chunks so that every LDS access is conflict-free.
+//   * page gather: one wave per tile resolves (page id, entry) of the 64 kv rows into a byte-offset table
+//     in LDS, two tiles ahead; K and V share it.
 // Softmax arithmetic (ref hopper/attention_updater.cuh:167-256): row sum from the UNROUNDED probabilities,
 // O *= scale_v / 448 / rowsum at the end, lse = m + log2(sum) in base 2.
 #pragma once
@@ -26,6 +28,7 @@
 namespace fi {
 
 using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x2 = __attribute__((ext_vector_type(2))) int;
 
 __device__ __forceinline__ f32x16 mfma_fp8_k64(i32x8 a, i32x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, /*A fmt e4m3*/ 0, /*B fmt e4m3*/ 0, 0,
@@ -41,13 +44,14 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     batch_prefill_fp8_kernel(const PrefillKernelParams p) {
   constexpr int D = 128;
   constexpr int K_ROWB = 128;               // bytes per row of the K image (one kv row)
-  constexpr int V_ROWB = 64;                // bytes per row of the V^T image (one head_dim row)
+  constexpr int V_ROWB = 128;               // bytes per row of the V image (one kv row)
   constexpr int K_TILE = kTileKV * K_ROWB;  // 8 KB
-  constexpr int V_TILE = D * V_ROWB;        // 8 KB
+  constexpr int V_TILE = kTileKV * V_ROWB;  // 8 KB
   constexpr int STAGE = K_TILE + V_TILE;
   constexpr int DBLK = D / 32;
 
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ uint64_t row_off_tab[4][kTileKV];  // byte offset of every kv row of a tile; slot = tile % 4
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -129,75 +133,44 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
   const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
 
-  // ---- staging geometry ----
-  // K: thread -> (row = tid/8 + 32 pass, 16-byte chunk tid%8), 2 passes
-  // V: thread -> (kv group kg = tid/32 + 8 pass (4 rows each), d group dg = tid%32 (4 bytes)), 2 passes
+  // ---- staging geometry: K and V alike, thread -> (row = tid/8 + 32 pass, 16-byte chunk tid%8) ----
   const int k_row = tid >> 3, k_ch = tid & 7;
-  const int v_kg = tid >> 5, v_dg = tid & 31;
   const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
+  const char* const k_thr = (const char*)p.k + head_off + k_ch * 16;
+  const char* const v_thr = (const char*)p.v + head_off + k_ch * 16;
   const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
-
-  // page ids: entries 0,1 = K passes, 2,3 = V passes (one page per 4-row group: page_size % 4 == 0)
-  auto fetch_pages = [&](int tile, int (&pg)[4], int (&en)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = i < 2 ? (k_row + 32 * i) : 4 * (v_kg + 8 * (i - 2));
-      const int kvi = max(min(tile * kTileKV + row, kv_len - 1), 0);
-      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
-      en[i] = kvi - pi * p.page_size;
-      pg[i] = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
-    }
+  auto tab_lookup = [&](int tile, int& pg, int& en) {
+    const int kvi = max(min(tile * kTileKV + lane, kv_len - 1), 0);
+    const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+    en = kvi - pi * p.page_size;
+    pg = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
+  };
+  auto tab_store = [&](int slot, int pg, int en) {
+    row_off_tab[slot][lane] = (uint64_t)(uint32_t)pg * stride_page32 + (uint64_t)(uint32_t)en * stride_n32;
   };
   struct Stage {
-    u32x4 k[2];
-    uint32_t v[2][4];
+    u32x4 k[2], v[2];
   };
-  auto issue_loads = [&](int tile, const int (&pg)[4], const int (&en)[4], Stage& st) {
+  auto issue_loads = [&](int slot, Stage& st) {
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      const int64_t off = (int64_t)((uint64_t)(uint32_t)pg[ps] * stride_page32 +
-                                    (uint64_t)(uint32_t)en[ps] * stride_n32) + head_off + k_ch * 16;
-      st.k[ps] = *(const u32x4*)((const uint8_t*)p.k + off);
-    }
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int64_t base = (int64_t)((uint64_t)(uint32_t)pg[2 + ps] * stride_page32 +
-                                     (uint64_t)(uint32_t)en[2 + ps] * stride_n32) + head_off + v_dg * 4;
-      // rows beyond kv_len are clamped to the last valid row (their probabilities are masked to 0)
-      const int row0v = tile * kTileKV + 4 * (v_kg + 8 * ps);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int di = min(row0v + i, kv_len - 1) - min(row0v, kv_len - 1);  // 0..3, clamped
-        st.v[ps][i] = *(const uint32_t*)((const uint8_t*)p.v + base + (int64_t)di * stride_n32);
-      }
+      const uint64_t off = row_off_tab[slot][k_row + 32 * ps];
+      st.k[ps] = *(const u32x4*)(k_thr + off);
+      st.v[ps] = *(const u32x4*)(v_thr + off);
     }
   };
   auto k_lds_off = [](int row, int ch) { return row * K_ROWB + ((ch ^ ((row >> 1) & 7)) << 4); };
+  // V chunk swizzle: the 8 rows of one transposed read are r0 + {0..3, 8..11}; bits 1 and 3 of the row
+  // tell the four rows of either parity apart
+  auto v_swz = [](int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); };
   auto write_stage = [&](int buf, const Stage& st) {
     char* kb = smem + buf * STAGE;
     char* vb = kb + K_TILE;
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) *(u32x4*)(kb + k_lds_off(k_row + 32 * ps, k_ch)) = st.k[ps];
-#pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-      const uint32_t r0 = st.v[ps][0], r1 = st.v[ps][1], r2 = st.v[ps][2], r3 = st.v[ps][3];
-      // 4x4 byte transpose: out[c] = (r0[c], r1[c], r2[c], r3[c])
-      const uint32_t t01l = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
-      const uint32_t t01h = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
-      const uint32_t t23l = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
-      const uint32_t t23h = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
-      uint32_t out[4];
-      out[0] = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);
-      out[1] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
-      out[2] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
-      out[3] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
-      // kv0 = 4 kg = 32 kbk + 8 g + 4 h  ->  slot = 2 h + kbk, in-slot byte 4 g
-      const int kg = v_kg + 8 * ps;
-      const int kbk = kg >> 3, g = (kg >> 1) & 3, h = kg & 1;
-      const int slot = (2 * h + kbk) ^ (v_dg & 3);
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        *(uint32_t*)(vb + (4 * v_dg + c) * V_ROWB + (slot << 4) + 4 * g) = out[c];
+      const int row = k_row + 32 * ps;
+      *(u32x4*)(kb + k_lds_off(row, k_ch)) = st.k[ps];
+      *(u32x4*)(vb + row * V_ROWB + ((k_ch ^ v_swz(row)) << 4)) = st.v[ps];
     }
   };
 
@@ -207,9 +180,19 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
     for (int e = 0; e < 2; ++e) k_rd[kk][e] = k_lds_off(lq, 4 * kk + 2 * lh + e);
-  int v_rd[2];  // V^T row lq (+32 db): slots 2 lh (+1), swizzled by (d >> 2) & 3
+  // V^T fragment (A operand): lane (d = 32 db + 16 g + j, lh) needs, as byte p = 8 r + b of its 32 bytes,
+  // V[kv(p)][d] with kv(p) = 32 (p >> 4) + 8 ((p & 15) >> 2) + 4 lh + (p & 3) -- the order in which the
+  // S^T accumulator registers hold P.  Transposed read r covers p = 8 r .. 8 r + 7: rows
+  // 32 (r >> 1) + 16 (r & 1) + 4 lh + {0..3, 8..11}; lane i of the 16-lane group addresses row b = i >> 1,
+  // bytes 8 (i & 1) .. +8 of chunk 2 db + g.
+  int v_rd[DBLK];
+  {
+    const int i16 = lane & 15, g = (lane >> 4) & 1, b = i16 >> 1;
+    const int row = 4 * lh + (b & 3) + 8 * (b >> 2);
 #pragma unroll
-  for (int e = 0; e < 2; ++e) v_rd[e] = lq * V_ROWB + (((2 * lh + e) ^ ((lq >> 2) & 3)) << 4);
+    for (int db = 0; db < DBLK; ++db)
+      v_rd[db] = row * V_ROWB + (((2 * db + g) ^ v_swz(row)) << 4) + 8 * (i16 & 1);
+  }
 
   f32x16 o_acc[DBLK];
 #pragma unroll
@@ -219,25 +202,24 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   float m_run = -1.0e30f, l_run = 0.f;
 
   if (num_tiles > 0) {
-    int pgA[4], enA[4], pgB[4], enB[4];
     Stage st;
-    fetch_pages(0, pgA, enA);
-    issue_loads(0, pgA, enA, st);
-    fetch_pages(1, pgB, enB);
+    if (wave < 2) {
+      int pg0, en0;
+      tab_lookup(min(wave, num_tiles - 1), pg0, en0);
+      tab_store(wave, pg0, en0);
+    }
+    __syncthreads();
+    issue_loads(0, st);
     write_stage(0, st);
     __syncthreads();
+    // The next tile is always staged (past the end: the last tile again, into the idle buffer), so there
+    // is no branch around a load.  The row-offset table of tile t+2 is produced during tile t by wave t % 4.
     auto tile_body = [&](auto buf_c, const int t) {
       constexpr int buf = decltype(buf_c)::value;
-      const bool has_next = t + 1 < num_tiles;
-      if (has_next) {
-        if constexpr (buf == 0) {
-          issue_loads(t + 1, pgB, enB, st);
-          fetch_pages(t + 2, pgA, enA);
-        } else {
-          issue_loads(t + 1, pgA, enA, st);
-          fetch_pages(t + 2, pgB, enB);
-        }
-      }
+      issue_loads((t + 1) & 3, st);
+      const bool tab_wave = wave == (t & 3);
+      int tab_pg = 0, tab_en = 0;
+      if (tab_wave) tab_lookup(min(t + 2, num_tiles - 1), tab_pg, tab_en);
       const char* kb = smem + buf * STAGE;
       const char* vb = kb + K_TILE;
       const int tile0 = t * kTileKV;
@@ -309,16 +291,22 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
         p8[j] = w;
       }
 
-      // ---- O^T += V^T P^T: one K=64 MFMA per 32 rows of head_dim ----
+      // ---- O^T += V^T P^T: one K=64 MFMA per 32 rows of head_dim, A gathered by 4 transposed reads ----
 #pragma unroll
       for (int db = 0; db < DBLK; ++db) {
-        const u32x4 lo = *(const u32x4*)(vb + db * 32 * V_ROWB + v_rd[0]);
-        const u32x4 hi = *(const u32x4*)(vb + db * 32 * V_ROWB + v_rd[1]);
-        const i32x8 a = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        i32x8 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const i32x2 w = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+              (__attribute__((address_space(3))) i32x2*)(vb + (32 * (r >> 1) + 16 * (r & 1)) * V_ROWB + v_rd[db]));
+          a[2 * r] = w[0];
+          a[2 * r + 1] = w[1];
+        }
         o_acc[db] = mfma_fp8_k64(a, p8, o_acc[db]);
       }
 
-      if (has_next) write_stage(buf ^ 1, st);
+      write_stage(buf ^ 1, st);
+      if (tab_wave) tab_store((t + 2) & 3, tab_pg, tab_en);
       __syncthreads();
     };
     int t = 0;
