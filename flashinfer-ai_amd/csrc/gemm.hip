@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
   const int wm = wave & 1, wn = wave >> 1;
   const int lq = lane & 31, lh = lane >> 5;
 
-  // ---- tile assignment: XCD-contiguous logical id; n tile fastest so that an A tile is reused ----
+  // ---- tile assignment: XCD-contiguous logical id ----
   const int total = p.num_m_tiles_bound * p.n_tiles;
   int logical;
   {
@@ -72,8 +72,17 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
     const int qn = total >> 3, rn = total & 7;
     logical = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
   }
-  const int mt_global = logical / p.n_tiles;
-  const int nt = logical - mt_global * p.n_tiles;
+  // Banded order inside the XCD's range: kBandM m tiles x all n tiles per band, m fastest.  The ~64
+  // workgroups an XCD runs at a time then cover an 8 x 8 block of output tiles (16 operand tiles in L2 for
+  // 64 products) instead of one m row (65 operand tiles): at C4 the B matrix of a group is streamed 4x
+  // instead of 32x.
+  constexpr int kBandM = 8;
+  const int band_tiles = kBandM * p.n_tiles;
+  const int band = logical / band_tiles;
+  const int in_band = logical - band * band_tiles;
+  const int band_m = min(kBandM, p.num_m_tiles_bound - band * kBandM);
+  const int nt = in_band / band_m;
+  const int mt_global = band * kBandM + (in_band - nt * band_m);
   // (group, m tile) from the running count of m tiles (ref: arg-prep kernel
   // group_gemm_fp8_groupwise_sm100.cuh:35-72 computes per-group problem sizes on the device too)
   int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
