@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace fi {
@@ -114,23 +116,36 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
   // ---- staging geometry: 4 passes of 32 rows x 8 chunks ----
   const int st_row = tid >> 3, st_ch = tid & 7;
   auto lds_off = [](int row, int ch) { return row * kBK + ((ch ^ ((row >> 1) & 7)) << 4); };
-  u32x4 ra[4], rb[4];
-  auto issue = [&](int kb) {
+  // global loads run one k block ahead of the MFMAs, through registers; the k block past the end re-loads
+  // the last one (no branch around a load)
+  struct StageRegs {
+    u32x4 a[4], b[4];
+  };
+  StageRegs rs;
+  // uniform tile bases + 32-bit per-thread row offsets (128 rows x K bytes < 2^32, checked on the host)
+  const uint8_t* const a_tile = p.a + (int64_t)m0 * K;
+  const uint8_t* const b_tile = Bg + (int64_t)n0 * K;
+  uint32_t a_off[4], b_off[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = ps * 32 + st_row;
+    a_off[ps] = (uint32_t)(min(m0 + row, m_end - 1) - m0) * (uint32_t)K + st_ch * 16;
+    b_off[ps] = (uint32_t)(min(n0 + row, N - 1) - n0) * (uint32_t)K + st_ch * 16;
+  }
+  auto issue = [&](int kb, StageRegs& r) {
+    const uint32_t koff = (uint32_t)(min(kb, kblocks - 1) * kBK);
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
-      const int row = ps * 32 + st_row;
-      const int am = min(m0 + row, m_end - 1);
-      const int bn = min(n0 + row, N - 1);
-      ra[ps] = *(const u32x4*)(p.a + (int64_t)am * K + kb * kBK + st_ch * 16);
-      rb[ps] = *(const u32x4*)(Bg + (int64_t)bn * K + kb * kBK + st_ch * 16);
+      r.a[ps] = *(const u32x4*)(a_tile + (a_off[ps] + koff));
+      r.b[ps] = *(const u32x4*)(b_tile + (b_off[ps] + koff));
     }
   };
-  auto commit = [&](int buf) {
+  auto commit = [&](int buf, const StageRegs& r) {
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int row = ps * 32 + st_row;
-      *(u32x4*)(&smem[buf][0][lds_off(row, st_ch)]) = ra[ps];
-      *(u32x4*)(&smem[buf][1][lds_off(row, st_ch)]) = rb[ps];
+      *(u32x4*)(&smem[buf][0][lds_off(row, st_ch)]) = r.a[ps];
+      *(u32x4*)(&smem[buf][1][lds_off(row, st_ch)]) = r.b[ps];
     }
   };
   // scales: a per lane (its m column), b per workgroup n tile
@@ -158,18 +173,55 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
 #pragma unroll
   for (int mb = 0; mb < 2; ++mb) m_lane[mb] = min(m0 + 64 * wm + 32 * mb + lq, m_end - 1);
 
-  issue(0);
-  commit(0);
+  issue(0, rs);
+  commit(0, rs);
   __syncthreads();
-  for (int kb = 0; kb < kblocks; ++kb) {
-    const int buf = kb & 1;
-    const bool has_next = kb + 1 < kblocks;
-    if (has_next) issue(kb + 1);
+  auto k_step = [&](auto par_c, const int kb) {
+    constexpr int buf = decltype(par_c)::value;  // == kb & 1
+    issue(kb + 1, rs);
     float sa[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) sa[mb] = a_scale_at(kb, m_lane[mb]);
     const float sb = b_scale_at(kb);
 
+    if constexpr (MX) {
+      // A fragments of the whole k block stay in registers; the two 32-column halves of the wave's tile
+      // are then processed one after the other, each with its own 32-register partial product, so that
+      // folding half 0 into the accumulator (vector pipe) runs beside the MFMAs of half 1 (matrix pipe)
+      i32x8g fa[2][2];  // [kk][mb]: this lane holds bytes [64 kk + 32 lh, +32) of its row
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const u32x4 lo = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 4 * kk + 2 * lh)]);
+          const u32x4 hi = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 4 * kk + 2 * lh + 1)]);
+          fa[kk][mb] = i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+        }
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        f32x16g part[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[mb][r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const u32x4 lo = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 4 * kk + 2 * lh)]);
+          const u32x4 hi = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 4 * kk + 2 * lh + 1)]);
+          const i32x8g fb = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+#pragma unroll
+          for (int mb = 0; mb < 2; ++mb)
+            part[mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
+                fb, fa[kk][mb], part[mb], MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const float s = sa[mb] * sb;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[nb][mb][r] += s * part[mb][r];
+        }
+      }
+    } else {
     f32x16g part[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -177,30 +229,6 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
-    if constexpr (MX) {
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {  // 64 bytes of k per step: this lane holds bytes [64 kk + 32 lh, +32)
-        i32x8g fa[2], fb[2];
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) {
-          const u32x4 lo = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 4 * kk + 2 * lh)]);
-          const u32x4 hi = *(const u32x4*)(&smem[buf][0][lds_off(64 * wm + 32 * mb + lq, 4 * kk + 2 * lh + 1)]);
-          fa[mb] = i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-        }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-          const u32x4 lo = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 4 * kk + 2 * lh)]);
-          const u32x4 hi = *(const u32x4*)(&smem[buf][1][lds_off(64 * wn + 32 * nb + lq, 4 * kk + 2 * lh + 1)]);
-          fb[nb] = i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-        }
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-          for (int mb = 0; mb < 2; ++mb)
-            part[nb][mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(
-                fb[nb], fa[mb], part[nb][mb], MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-      }
-    } else {
 #pragma unroll
     for (int kp = 0; kp < 4; ++kp) {  // 32 bytes of k per step pair: bytes [32 kp + 16 lh, +16)
       u32x4 fa[2], fb[2];
@@ -223,7 +251,6 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
         }
       }
     }
-    }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -232,8 +259,17 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nb][mb][r] += s * part[nb][mb][r];
       }
-    if (has_next) commit(buf ^ 1);
+    }
+    commit(buf ^ 1, rs);
     __syncthreads();
+  };
+  {
+    int kb = 0;
+    for (; kb + 1 < kblocks; kb += 2) {
+      k_step(std::integral_constant<int, 0>{}, kb);
+      k_step(std::integral_constant<int, 1>{}, kb + 1);
+    }
+    if (kb < kblocks) k_step(std::integral_constant<int, 0>{}, kb);
   }
 
   // ---- epilogue: D[m][n], 4 consecutive n per lane and register quad ----
