@@ -71,8 +71,9 @@ __global__ void __launch_bounds__(kMergeThreads) merge_n_kernel(const MergeNPara
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) dsum += __shfl_xor(dsum, off, 64);
   const int64_t ob = ((int64_t)row * p.num_heads + head) * D;
-  // n == 0 -> zeros / -inf sentinel (ref: cascade.cuh:397-405)
-  const bool empty = !(dsum > 0.f);
+  // n == 0, or nothing but empty partial states -> zeros / -inf sentinel (ref: cascade.cuh:397-405)
+  if (n == 0 && p.skip_empty) return;
+  const bool empty = !(dsum > 0.f) || mx <= FI_NEG_INF;
   const float inv = empty ? 0.f : 1.0f / dsum;
 #pragma unroll
   for (int k = 0; k < kMergeMaxPerLane; ++k) {

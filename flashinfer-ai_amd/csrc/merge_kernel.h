@@ -21,6 +21,7 @@ struct MergeNParams {
   int32_t n_fixed;  // entries per row when indptr == NULL; layout [row, n, H, D]
   int32_t seq_len, num_heads, head_dim;
   int32_t in_dtype, out_dtype;
+  int32_t skip_empty;  // rows without entries are left untouched (padding rows of a fixed-shape launch)
 };
 
 struct Merge2Params {

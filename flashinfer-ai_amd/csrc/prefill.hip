@@ -6,6 +6,7 @@
 #include <numeric>
 #include <vector>
 
+#include "merge_kernel.h"
 #include "prefill_kernel.h"
 
 namespace fi {
@@ -69,11 +70,10 @@ extern "C" FI_API int fi_batch_prefill_plan(
     int32_t page_size, int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
     int32_t causal, int32_t window_left, int32_t fixed_split_size, int32_t disable_split_kv,
     int64_t* plan_info_out, fi_stream_t stream) {
-  (void)float_ws; (void)float_ws_bytes; (void)kv_indptr_h; (void)page_size; (void)window_left;
-  (void)fixed_split_size; (void)disable_split_kv;
+  (void)float_ws; (void)kv_indptr_h; (void)window_left;
   FI_REQUIRE(pinned_int_ws && qo_indptr_h && kv_len_arr_h && plan_info_out,
              "batch_prefill_plan: null argument");
-  FI_REQUIRE(batch_size >= 0, "batch_prefill_plan: negative batch size");
+  FI_REQUIRE(batch_size >= 0 && page_size > 0, "batch_prefill_plan: bad batch size / page size");
   FI_REQUIRE(num_kv_heads > 0 && num_qo_heads % num_kv_heads == 0,
              "batch_prefill_plan: num_qo_heads (%d) must be a multiple of num_kv_heads (%d)",
              num_qo_heads, num_kv_heads);
@@ -83,51 +83,127 @@ extern "C" FI_API int fi_batch_prefill_plan(
   FI_REQUIRE(qo_indptr_h[0] == 0, "batch_prefill_plan: qo_indptr[0] must be 0");
   const int group = num_qo_heads / num_kv_heads;
 
-  // work list: one item per 128-row tile of GQA-packed queries (ref: PrefillSplitQOKVIndptr,
-  // scheduler.cuh:495-614 with packed_qo_len = qo_len * G).  Items are ordered longest-first
-  // (requests by kv_len descending, and for causal masks the later = heavier q tiles first) so the
-  // tail of the launch is made of the cheapest items (ref LPT idea: scheduler.cuh:900-946).
+  // ---- q tiles and kv chunks (ref: PrefillSplitQOKVIndptr, scheduler.cuh:495-614, with
+  // packed_qo_len = qo_len * G and a fixed 128-row q tile) ----
+  std::vector<int64_t> q_tiles(batch_size), kv_len(batch_size);
+  int64_t total_q_tiles = 0, max_kv_len = 1;
+  for (int b = 0; b < batch_size; ++b) {
+    const int64_t qo_len = qo_indptr_h[b + 1] - qo_indptr_h[b];
+    FI_REQUIRE(qo_len >= 0, "batch_prefill_plan: qo_indptr must be non-decreasing");
+    FI_REQUIRE(kv_len_arr_h[b] >= 0, "batch_prefill_plan: negative kv length");
+    q_tiles[b] = ceil_div<int64_t>(qo_len * group, kTileQ);
+    kv_len[b] = std::max<int64_t>(kv_len_arr_h[b], 1);
+    total_q_tiles += q_tiles[b];
+    max_kv_len = std::max(max_kv_len, kv_len[b]);
+  }
+  // resident workgroups (2 per CU) over the kv heads each item is launched for
+  // (ref: max_batch_size_if_split = max_grid_size / num_kv_heads, scheduler.cuh:718)
+  const int64_t max_items = std::max<int64_t>((int64_t)fi_num_compute_units() * 2 / num_kv_heads, 1);
+  const int64_t graph_bound =
+      ceil_div<int64_t>((int64_t)total_num_rows * group, kTileQ) + std::max(batch_size, 1) - 1;
+  // chunk sizes are multiples of one 64-row kv tile and at least 128 tokens (ref: min_kv_chunk_size)
+  auto items_at = [&](int64_t chunk) {
+    int64_t n = 0;
+    for (int b = 0; b < batch_size; ++b) n += q_tiles[b] * ceil_div<int64_t>(kv_len[b], chunk);
+    return n;
+  };
+  const int64_t chunk_unit = kTileKV;
+  int64_t kv_chunk = ceil_div<int64_t>(max_kv_len, chunk_unit) * chunk_unit;  // one chunk = no split
+  bool split_kv = false;
+  if (!disable_split_kv && batch_size > 0) {
+    if (fixed_split_size > 0) {
+      kv_chunk = ceil_div<int64_t>(fixed_split_size, chunk_unit) * chunk_unit;
+    } else {
+      // ref: PrefillBinarySearchKVChunkSize, scheduler.cuh:101-130 (in units of 64 tokens)
+      int64_t low = 128 / chunk_unit, high = ceil_div<int64_t>(max_kv_len, chunk_unit);
+      while (low < high) {
+        const int64_t mid = (low + high) / 2;
+        if (items_at(mid * chunk_unit) > max_items) low = mid + 1; else high = mid;
+      }
+      kv_chunk = std::max<int64_t>(low, 128 / chunk_unit) * chunk_unit;
+    }
+    split_kv = kv_chunk < max_kv_len;
+    // a fixed-shape (graph) launch always takes the split path so that the kernel sequence does not
+    // depend on the page table (ref: scheduler.cuh:129)
+    if (enable_cuda_graph) split_kv = true;
+  }
+  FI_REQUIRE(kv_chunk < (1ll << 31), "batch_prefill_plan: kv chunk too large");
+
+  // work list, longest first (requests by kv_len descending; for causal masks the later = heavier q
+  // tiles first) so the tail of the launch is made of the cheapest items (ref LPT idea: scheduler.cuh:900-946)
   std::vector<int> order(batch_size);
   std::iota(order.begin(), order.end(), 0);
   std::stable_sort(order.begin(), order.end(),
                    [&](int a, int b) { return kv_len_arr_h[a] > kv_len_arr_h[b]; });
-  std::vector<int32_t> req, tile;
+  std::vector<int32_t> req, tile, kvt;
   for (int b : order) {
-    const int64_t qo_len = qo_indptr_h[b + 1] - qo_indptr_h[b];
-    FI_REQUIRE(qo_len >= 0, "batch_prefill_plan: qo_indptr must be non-decreasing");
-    const int64_t ntiles = ceil_div<int64_t>(qo_len * group, kTileQ);
-    for (int64_t t = 0; t < ntiles; ++t) {
-      req.push_back(b);
-      tile.push_back((int32_t)(causal ? ntiles - 1 - t : t));
-    }
+    const int64_t ntiles = q_tiles[b];
+    const int64_t nchunks = split_kv ? ceil_div<int64_t>(kv_len[b], kv_chunk) : 1;
+    for (int64_t t = 0; t < ntiles; ++t)
+      for (int64_t c = 0; c < nchunks; ++c) {
+        req.push_back(b);
+        tile.push_back((int32_t)(causal ? ntiles - 1 - t : t));
+        kvt.push_back((int32_t)c);
+      }
   }
   size_t padded = req.size();
-  if (enable_cuda_graph) {
-    // fixed launch shape: the most tiles total_num_rows rows can ever form
-    const size_t bound = (size_t)ceil_div<int64_t>((int64_t)total_num_rows * group, kTileQ) + batch_size;
-    padded = std::max(padded, bound);
-  }
+  if (enable_cuda_graph) padded = std::max<size_t>(padded, (size_t)std::max(max_items, graph_bound));
+  // partial-state ranges per qo row (ref merge_indptr, scheduler.cuh:597-600)
+  const int64_t nrows_tab = split_kv ? (int64_t)std::max(total_num_rows, qo_indptr_h[batch_size]) : 0;
   OffsetAllocator ia(int_ws_bytes);
   const int64_t req_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
   const int64_t tile_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
+  const int64_t kvt_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
+  const int64_t mrg_off = ia.alloc((size_t)(nrows_tab + 1) * sizeof(int32_t));
   FI_REQUIRE(ia.ok, "batch_prefill_plan: int workspace too small (%zu bytes)", int_ws_bytes);
   int32_t* req_h = (int32_t*)((char*)pinned_int_ws + req_off);
   int32_t* tile_h = (int32_t*)((char*)pinned_int_ws + tile_off);
+  int32_t* kvt_h = (int32_t*)((char*)pinned_int_ws + kvt_off);
+  int32_t* mrg_h = (int32_t*)((char*)pinned_int_ws + mrg_off);
   for (size_t i = 0; i < padded; ++i) {
     req_h[i] = i < req.size() ? req[i] : -1;  // -1: padding item, the workgroup exits
     tile_h[i] = i < tile.size() ? tile[i] : 0;
+    kvt_h[i] = i < kvt.size() ? kvt[i] : 0;
+  }
+  int64_t entries = 0;
+  mrg_h[0] = 0;
+  if (split_kv) {
+    int64_t row = 0;
+    for (int b = 0; b < batch_size; ++b) {
+      const int64_t nchunks = ceil_div<int64_t>(kv_len[b], kv_chunk);
+      for (int64_t r = qo_indptr_h[b]; r < qo_indptr_h[b + 1]; ++r) {
+        entries += nchunks;
+        mrg_h[++row] = (int32_t)entries;
+      }
+    }
+    FI_REQUIRE(entries < (1ll << 31), "batch_prefill_plan: too many partial states");
+    for (; row < nrows_tab; ) mrg_h[++row] = (int32_t)entries;  // padded rows of a graph launch: empty
+  }
+  int64_t v_off = 0, s_off = 0;
+  if (split_kv) {
+    OffsetAllocator fa(float_ws_bytes);
+    v_off = fa.alloc((size_t)std::max<int64_t>(entries, 1) * num_qo_heads * head_dim_vo * sizeof(float));
+    s_off = fa.alloc((size_t)std::max<int64_t>(entries, 1) * num_qo_heads * sizeof(float));
+    FI_REQUIRE(fa.ok, "batch_prefill_plan: float workspace too small (%zu bytes, need %zu for %lld partial "
+               "states)", float_ws_bytes,
+               (size_t)entries * num_qo_heads * (head_dim_vo + 1) * sizeof(float), (long long)entries);
   }
   for (int i = 0; i < FI_PREFILL_PLAN_INFO_LEN; ++i) plan_info_out[i] = 0;
   plan_info_out[FI_PP_PADDED_BATCH_SIZE] = (int64_t)padded;
-  plan_info_out[FI_PP_TOTAL_NUM_ROWS] = total_num_rows;
+  plan_info_out[FI_PP_TOTAL_NUM_ROWS] = split_kv ? nrows_tab : total_num_rows;
   plan_info_out[FI_PP_CTA_TILE_Q] = kTileQ;
   plan_info_out[FI_PP_REQUEST_INDICES_OFFSET] = req_off;
   plan_info_out[FI_PP_QO_TILE_INDICES_OFFSET] = tile_off;
+  plan_info_out[FI_PP_KV_TILE_INDICES_OFFSET] = kvt_off;
+  plan_info_out[FI_PP_MERGE_INDPTR_OFFSET] = mrg_off;
+  plan_info_out[FI_PP_BATCH_SIZE] = batch_size;
+  plan_info_out[FI_PP_KV_CHUNK_SIZE] = kv_chunk;
+  plan_info_out[FI_PP_V_OFFSET] = v_off;
+  plan_info_out[FI_PP_S_OFFSET] = s_off;
+  plan_info_out[FI_PP_NUM_WORK] = (int64_t)req.size();
   plan_info_out[FI_PP_ENABLE_CUDA_GRAPH] = enable_cuda_graph ? 1 : 0;
-  plan_info_out[FI_PP_SPLIT_KV] = 0;
+  plan_info_out[FI_PP_SPLIT_KV] = split_kv ? 1 : 0;
   plan_info_out[FI_PP_MAGIC] = FI_PREFILL_PLAN_MAGIC;
-  plan_info_out[6] = batch_size;
-  plan_info_out[7] = (int64_t)req.size();
   if (int_ws && ia.used)
     FI_HIP_CALL(hipMemcpyAsync(int_ws, pinned_int_ws, ia.used, hipMemcpyHostToDevice,
                                (hipStream_t)stream));
@@ -154,7 +230,7 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
                                                  int32_t plan_info_len,
                                                  const fi_batch_prefill_params_t* a,
                                                  fi_stream_t stream_) {
-  (void)float_ws; (void)float_ws_bytes; (void)int_ws_bytes;
+  (void)int_ws_bytes;
   hipStream_t stream = (hipStream_t)stream_;
   FI_REQUIRE(plan_info && plan_info_len == FI_PREFILL_PLAN_INFO_LEN &&
                  plan_info[FI_PP_MAGIC] == FI_PREFILL_PLAN_MAGIC,
@@ -167,7 +243,7 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   FI_REQUIRE(a->q && a->o && a->qo_indptr && kv.k_data && kv.v_data && kv.indptr,
              "batch_prefill_paged_run: null tensor");
   FI_REQUIRE(kv.last_page_len || !kv.indices, "batch_prefill_paged_run: a page table needs last_page_len");
-  FI_REQUIRE(kv.batch_size == plan_info[6], "batch_prefill_paged_run: batch size differs from the plan");
+  FI_REQUIRE(kv.batch_size == plan_info[FI_PP_BATCH_SIZE], "batch_prefill_paged_run: batch size differs from the plan");
   FI_REQUIRE(kv.num_kv_heads > 0 && a->num_qo_heads % kv.num_kv_heads == 0,
              "batch_prefill_paged_run: num_qo_heads must be a multiple of num_kv_heads");
   FI_REQUIRE(a->mask_mode >= FI_MASK_NON_CAUSAL && a->mask_mode <= FI_MASK_CUSTOM,
@@ -205,6 +281,17 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.kv_last_page_len = kv.last_page_len;
   kp.request_indices = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_REQUEST_INDICES_OFFSET]);
   kp.qo_tile_indices = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_QO_TILE_INDICES_OFFSET]);
+  const bool split = plan_info[FI_PP_SPLIT_KV] != 0;
+  if (split) {
+    FI_REQUIRE(float_ws, "batch_prefill_paged_run: a split-kv plan needs the float workspace");
+    FI_REQUIRE((size_t)plan_info[FI_PP_S_OFFSET] <= float_ws_bytes,
+               "batch_prefill_paged_run: float workspace smaller than at plan()");
+    kp.kv_tile_indices = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_KV_TILE_INDICES_OFFSET]);
+    kp.merge_indptr = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_MERGE_INDPTR_OFFSET]);
+    kp.tmp_o = (float*)((char*)float_ws + plan_info[FI_PP_V_OFFSET]);
+    kp.tmp_lse = (float*)((char*)float_ws + plan_info[FI_PP_S_OFFSET]);
+    kp.kv_chunk_size = (int32_t)plan_info[FI_PP_KV_CHUNK_SIZE];
+  }
   kp.alibi_slopes = a->alibi_slopes;
   kp.scale_q = a->scale_q;
   kp.scale_k = a->scale_k;
@@ -236,9 +323,16 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.rope_rcp_theta = a->rope_rcp_theta;
   if (use_fp8_native(kp, a->q_dtype, kv.dtype, kv.head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA)) {
     FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, stream));
-    return 0;
+  } else {
+    FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
   }
-  FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
+  if (split) {
+    // ref: VariableLengthMergeStates after the partition-kv kernel, prefill.cuh:2590-2671
+    MergeNParams mp{kp.tmp_o, kp.tmp_lse, kp.merge_indptr, a->o, a->lse, 0,
+                    (int32_t)plan_info[FI_PP_TOTAL_NUM_ROWS], a->num_qo_heads, kv.head_dim, FI_DTYPE_F32,
+                    a->o_dtype, /*skip_empty=*/1};
+    FI_HIP_CALL(launch_merge_n(mp, stream));
+  }
   return 0;
 }
 

@@ -127,9 +127,18 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
-  const int num_tiles = (kv_end + kTileKV - 1) / kTileKV;
-  const int vis_hi = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
-  const int vis_lo = 0;
+  int kv_begin = 0, kv_chunk = 0;
+  if (p.kv_tile_indices) {  // split-KV work item (see prefill_kernel.h)
+    kv_chunk = p.kv_tile_indices[work];
+    kv_begin = kv_chunk * p.kv_chunk_size;
+    kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
+  }
+  const int tile_base = kv_begin / kTileKV;
+  const int num_tiles = kv_end > kv_begin ? (kv_end - kv_begin + kTileKV - 1) / kTileKV : 0;
+  // a row that sees no key (causal with qo_len > kv_len) gets a range no index can fall into
+  const int vis_hi_raw = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
+  const int vis_lo = vis_hi_raw < 0 ? 0x40000000 : 0;
+  const int vis_hi = vis_hi_raw < 0 ? 0x40000000 : vis_hi_raw;
   const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
   const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
 
@@ -205,7 +214,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     Stage st;
     if (wave < 2) {
       int pg0, en0;
-      tab_lookup(min(wave, num_tiles - 1), pg0, en0);
+      tab_lookup(tile_base + min(wave, num_tiles - 1), pg0, en0);
       tab_store(wave, pg0, en0);
     }
     __syncthreads();
@@ -219,10 +228,10 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
       issue_loads((t + 1) & 3, st);
       const bool tab_wave = wave == (t & 3);
       int tab_pg = 0, tab_en = 0;
-      if (tab_wave) tab_lookup(min(t + 2, num_tiles - 1), tab_pg, tab_en);
+      if (tab_wave) tab_lookup(tile_base + min(t + 2, num_tiles - 1), tab_pg, tab_en);
       const char* kb = smem + buf * STAGE;
       const char* vb = kb + K_TILE;
-      const int tile0 = t * kTileKV;
+      const int tile0 = (tile_base + t) * kTileKV;
 
       // ---- S^T = K Q^T: 2 kv blocks x 2 k-steps of 64 ----
       f32x16 s_acc[2];
@@ -322,7 +331,22 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
   if (p.scale_v) inv *= p.scale_v[kv_head];
-  if (row_valid) {
+  if (row_valid && p.kv_tile_indices) {
+    const int64_t entry = (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk;
+    const int64_t ob = (entry * p.num_qo_heads + qo_head) * D;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = 32 * db + 8 * r4 + 4 * lh;
+        *(f32x4*)(p.tmp_o + ob + d0) = f32x4{o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv,
+                                             o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv};
+      }
+    }
+    if (lh == 0)
+      p.tmp_lse[entry * p.num_qo_heads + qo_head] =
+          empty ? FI_NEG_INF : m_run + fast_log2(l_run) - 8.807354922057604f;
+  } else if (row_valid) {
     const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {

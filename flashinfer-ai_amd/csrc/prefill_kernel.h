@@ -45,6 +45,13 @@ struct PrefillKernelParams {
   const int32_t* kv_last_page_len;
   const int32_t* request_indices;  // work list (NULL: request 0, tile = work index)
   const int32_t* qo_tile_indices;
+  // split-KV (ref: scheduler.cuh:495-614): work item = (request, q tile, kv chunk); partial states go to
+  // tmp_o / tmp_lse at entry merge_indptr[qo row] + kv chunk and are folded by the n-way merge kernel
+  const int32_t* kv_tile_indices;  // NULL: no split
+  const int32_t* merge_indptr;     // [total qo rows + 1]
+  float* tmp_o;
+  float* tmp_lse;
+  int32_t kv_chunk_size;           // tokens, a multiple of the 64-row kv tile
   const float* alibi_slopes;
   const float* scale_q;  // fp8: per qo head / kv head scales (NULL = 1)
   const float* scale_k;
@@ -296,11 +303,21 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
     const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
-  const int num_tiles = (kv_end + kTileKV - 1) / kTileKV;
-  // visible kv index range of this lane's query row (ref: prefill.cuh:782-786, variants.cuh:87-89);
-  // an empty range (vis_hi < vis_lo) can only arise from kv_len == 0, which runs no tile
-  const int vis_hi = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
-  const int vis_lo = p.window_left >= 0 ? max(q_pos - p.window_left, 0) : 0;
+  int kv_begin = 0, kv_chunk = 0;
+  if (p.kv_tile_indices) {
+    kv_chunk = p.kv_tile_indices[work];
+    kv_begin = kv_chunk * p.kv_chunk_size;
+    kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
+  }
+  const int tile_base = kv_begin / kTileKV;  // chunks start on tile boundaries
+  const int num_tiles = kv_end > kv_begin ? (kv_end - kv_begin + kTileKV - 1) / kTileKV : 0;
+  // visible kv index range of this lane's query row (ref: prefill.cuh:782-786, variants.cuh:87-89).  A row
+  // that sees no key at all (causal with qo_len > kv_len: q_pos < 0) gets a range no index can fall into.
+  const int vis_hi_raw = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
+  const int vis_lo_raw = p.window_left >= 0 ? max(q_pos - p.window_left, 0) : 0;
+  const bool sees_none = vis_hi_raw < vis_lo_raw;
+  const int vis_lo = sees_none ? 0x40000000 : vis_lo_raw;
+  const int vis_hi = sees_none ? 0x40000000 : vis_hi_raw;  // span 0 around an unreachable index
   // smallest query position of this WAVE (wave-uniform): tiles ending at or below it need no causal mask
   const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
   const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
@@ -438,14 +455,14 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
     Stage kst, vst;
     if (wave < 3) {
       int pg0, en0;
-      tab_lookup(min(wave, num_tiles - 1), pg0, en0);
+      tab_lookup(tile_base + min(wave, num_tiles - 1), pg0, en0);
       tab_store(wave, pg0, en0);
     }
     __syncthreads();
     read_offsets(0, roff);
     issue_loads(k_thr, roff, kst);
     issue_loads(v_thr, roff, vst);
-    write_k(0, 0, kst);
+    write_k(tile_base, 0, kst);
     write_v(0, vst);
     read_offsets(1, roff);
     issue_loads(k_thr, roff, kst);
@@ -455,16 +472,16 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
     // into the idle buffer): no branch around a load, so the compiler's vmcnt counts stay exact.
     auto tile_body = [&](auto buf_c, const int t) {
       constexpr int buf = decltype(buf_c)::value;
-      const int t_next = min(t + 1, num_tiles - 1);
+      const int t_next = tile_base + min(t + 1, num_tiles - 1);
       write_k(t_next, buf ^ 1, kst);     // K rows of tile t+1 (loaded during tile t-1)
       read_offsets((t + 2) & 3, roff);
       issue_loads(k_thr, roff, kst);     // K rows of tile t+2
       const bool tab_wave = wave == (t & 3);
       int tab_pg = 0, tab_en = 0;
-      if (tab_wave) tab_lookup(min(t + 3, num_tiles - 1), tab_pg, tab_en);
+      if (tab_wave) tab_lookup(tile_base + min(t + 3, num_tiles - 1), tab_pg, tab_en);
       const char* kb = lds_base + buf * 2 * TILE_BYTES;
       const char* vb = kb + TILE_BYTES;
-      const int tile0 = t * kTileKV;
+      const int tile0 = (tile_base + t) * kTileKV;
 
       // ---- S^T = K Q^T ----
       // The 2 x KSTEPS K fragments are read kQkPrefetch MFMAs ahead of their use (the LDS round trip is 2-4
@@ -625,7 +642,21 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   float inv = empty ? 0.f : 1.0f / l_run;
   if constexpr (Q_FP8) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
   else if (p.scale_v) inv *= p.scale_v[kv_head];
-  if (row_valid) {
+  if (row_valid && p.kv_tile_indices) {
+    // partial state of this kv chunk: normalised f32 o + base-2 lse (ref: prefill.cuh:2378-2403)
+    const int64_t entry = (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk;
+    const int64_t ob = (entry * p.num_qo_heads + qo_head) * D;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) {
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int d0 = 32 * db + 8 * r4 + 4 * lh;
+        *(f32x4*)(p.tmp_o + ob + d0) = f32x4{o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv,
+                                             o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv};
+      }
+    }
+    if (lh == 0) p.tmp_lse[entry * p.num_qo_heads + qo_head] = empty ? FI_NEG_INF : m_run + fast_log2(l_run);
+  } else if (row_valid) {
     const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {

@@ -209,6 +209,13 @@ enum fi_prefill_plan_slot {
   FI_PP_CTA_TILE_Q = 3,
   FI_PP_REQUEST_INDICES_OFFSET = 4,
   FI_PP_QO_TILE_INDICES_OFFSET = 5,
+  FI_PP_KV_TILE_INDICES_OFFSET = 6, /* int workspace, valid when SPLIT_KV */
+  FI_PP_MERGE_INDPTR_OFFSET = 7,    /* int workspace: [total_num_rows + 1] partial-state ranges per qo row */
+  FI_PP_BATCH_SIZE = 8,
+  FI_PP_KV_CHUNK_SIZE = 9,          /* tokens */
+  FI_PP_V_OFFSET = 10,              /* float workspace: f32 partial outputs */
+  FI_PP_S_OFFSET = 11,              /* float workspace: f32 partial lse */
+  FI_PP_NUM_WORK = 12,              /* real work items (<= PADDED_BATCH_SIZE) */
   FI_PP_ENABLE_CUDA_GRAPH = 13,
   FI_PP_SPLIT_KV = 14,
   FI_PP_MAGIC = 15
@@ -216,8 +223,10 @@ enum fi_prefill_plan_slot {
 #define FI_PREFILL_PLAN_MAGIC 0x4649505245ll /* "FIPRE" */
 
 /* qo_indptr_h / kv_indptr_h: HOST [batch+1]; kv_len_arr_h: HOST [batch]. int_ws == NULL plans on the
- * host only.  fixed_split_size / disable_split_kv are accepted for API parity (this build never splits
- * the kv axis of a prefill work item, so results are batch-invariant by construction). */
+ * host only.  The kv axis is split into chunks when the (request, q tile) items alone cannot fill the chip
+ * (binary search of the chunk size as PrefillBinarySearchKVChunkSize, scheduler.cuh:101-130); partial states
+ * then go to the float workspace and are merged by run().  fixed_split_size (tokens, > 0) fixes the chunk
+ * size, disable_split_kv forbids splitting (batch-invariant results). */
 FI_API int fi_batch_prefill_plan(void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws,
                           size_t int_ws_bytes, const int32_t* qo_indptr_h, const int32_t* kv_indptr_h,
                           const int32_t* kv_len_arr_h, int32_t total_num_rows, int32_t batch_size,

@@ -264,3 +264,71 @@ def test_ragged_kv_prefill_wrapper(layout, causal):
         o_ref, lse_ref = R.attention_ref(qs, ks, vs, causal=causal)
         torch.testing.assert_close(o[int(qo_indptr[b]):int(qo_indptr[b + 1])].float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
         torch.testing.assert_close(lse[int(qo_indptr[b]):int(qo_indptr[b + 1])].cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+# ---- split-KV prefill (ref planner: PrefillSplitQOKVIndptr, scheduler.cuh:495-614) -----------------------
+def _plan_run(qo_lens, kv_lens, hq, hkv, d, ps, dtype, causal, seed, layout="NHD", **plan_kw):
+    import flashinfer
+
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, ps, hkv, d, dtype, layout, seed=seed)
+    torch.manual_seed(seed + 1)
+    q = torch.randn(sum(qo_lens), hq, d).to(dtype)
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    ws = torch.zeros(256 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, layout)
+    w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps, causal=causal,
+           q_data_type=dtype, kv_data_type=cache.dtype, **plan_kw)
+    o, lse = w.run(q.to(DEV), cache.to(DEV), return_lse=True)
+    return w, q, cache, qo_indptr, indptr, indices, last, o, lse
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("qo_lens,kv_lens", [([64], [9000]), ([5, 200, 1], [3000, 4097, 130]), ([300], [300])])
+def test_batch_prefill_split_kv_matches_oracle_and_unsplit(dtype, causal, qo_lens, kv_lens):
+    hq, hkv, d, ps = 8, 2, 128, 16
+    w, q, cache, qo_indptr, indptr, indices, last, o, lse = _plan_run(qo_lens, kv_lens, hq, hkv, d, ps, dtype,
+                                                                      causal, seed=50)
+    # few q tiles x 2 kv heads cannot fill 256 CUs: the planner must have split long kv
+    if max(kv_lens) >= 3000:
+        assert w._plan_info[14] == 1 and w._plan_info[9] % 64 == 0
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last,
+                                         causal=causal)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), **ptol(dtype))
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    # disable_split_kv (batch-invariant mode) and a fixed split size give the same answer
+    for kw in (dict(disable_split_kv=True), dict(fixed_split_size=512)):
+        w2, *_, o2, lse2 = _plan_run(qo_lens, kv_lens, hq, hkv, d, ps, dtype, causal, seed=50, **kw)
+        assert w2._plan_info[14] == (0 if "disable_split_kv" in kw else int(max(kv_lens) > 512))
+        torch.testing.assert_close(o2.float(), o.float(), **ptol(dtype))
+        torch.testing.assert_close(lse2, lse, rtol=1e-3, atol=1e-3)
+
+
+def test_batch_prefill_split_kv_fp8_native_and_rows_without_keys():
+    # fp8 attention through the split path against the unsplit run
+    hq, hkv, d, ps = 8, 2, 128, 16
+    qo_lens, kv_lens = [100], [8192]
+    w, q, cache, qo_indptr, indptr, indices, last, o, lse = _plan_run(
+        qo_lens, kv_lens, hq, hkv, d, ps, torch.float8_e4m3fn, True, seed=60, o_data_type=torch.bfloat16)
+    assert w._plan_info[14] == 1
+    w2, *_, o2, lse2 = _plan_run(qo_lens, kv_lens, hq, hkv, d, ps, torch.float8_e4m3fn, True, seed=60,
+                                 o_data_type=torch.bfloat16, disable_split_kv=True)
+    assert w2._plan_info[14] == 0
+    torch.testing.assert_close(o.float(), o2.float(), rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(lse, lse2, rtol=1e-2, atol=1e-2)
+    # causal with qo_len > kv_len: the first rows see no key in any chunk -> o = 0, lse = -5e4 exactly
+    qo_lens, kv_lens = [700], [600]
+    w, q, cache, qo_indptr, indptr, indices, last, o, lse = _plan_run(qo_lens, kv_lens, 4, 1, 128, 16,
+                                                                      torch.float16, True, seed=61,
+                                                                      fixed_split_size=128)
+    assert w._plan_info[14] == 1
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last,
+                                         causal=True)
+    assert torch.all(o[:100] == 0) and torch.all(lse[:100].cpu() == R.NEG_INF_SENTINEL)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    # the same rows through the unsplit kernel
+    w, *_, o, lse = _plan_run(qo_lens, kv_lens, 4, 1, 128, 16, torch.float16, True, seed=61, disable_split_kv=True)
+    assert w._plan_info[14] == 0
+    assert torch.all(o[:100] == 0) and torch.all(lse[:100].cpu() == R.NEG_INF_SENTINEL)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
