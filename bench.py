@@ -94,6 +94,68 @@ def cpu_baseline(cfg, sample_requests=8, iters=3):
     }
 
 
+def _time_ms(fn, iters, warm):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for s, e in ev:
+        s.record()
+        fn()
+        e.record()
+    torch.cuda.synchronize()
+    ts = sorted(s.elapsed_time(e) for s, e in ev)
+    return ts[len(ts) // 2]
+
+
+def secondary_workloads(device):
+    """BASELINE.json configs C3 (fp8 causal batch prefill) and C4 (fp8 groupwise grouped GEMM), timed on this
+    GPU after the headline run: reported next to it, never part of `value`.  FLOP formulas are the
+    reference's (flashinfer/testing/utils.py:280-297; benchmarks/bench_groupwise_grouped_gemm_fp8_blackwell.py:51);
+    peak = 5 PFLOP/s dense fp8 (MI355X_MICROARCH.md)."""
+    import flashinfer
+
+    out = []
+    g = torch.Generator(device=device).manual_seed(1)
+    # C3: fp8_e4m3 causal, qo_len 2048, kv_len 8192, bs 16, head_dim 128 (32/8 heads as C2), page 16
+    b, qo, kv, hq, hkv, d, ps = 16, 2048, 8192, 32, 8, 128, 16
+    npages = b * kv // ps
+    cache = torch.randn(npages, 2, ps, hkv, d, device=device, dtype=torch.bfloat16, generator=g).to(torch.float8_e4m3fn)
+    q = torch.randn(b * qo, hq, d, device=device, dtype=torch.bfloat16, generator=g).to(torch.float8_e4m3fn)
+    qo_indptr = (torch.arange(b + 1, dtype=torch.int32) * qo).to(device)
+    indptr = (torch.arange(b + 1, dtype=torch.int32) * (kv // ps)).to(device)
+    indices = torch.randperm(npages, device=device, generator=g).to(torch.int32)
+    last = torch.full((b,), ps, dtype=torch.int32, device=device)
+    ws = torch.zeros(128 << 20, dtype=torch.uint8, device=device)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, "NHD")
+    w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, causal=True, q_data_type=torch.float8_e4m3fn,
+           kv_data_type=torch.float8_e4m3fn, o_data_type=torch.bfloat16)
+    o = torch.empty(b * qo, hq, d, device=device, dtype=torch.bfloat16)
+    ms = _time_ms(lambda: w.run(q, cache, out=o), iters=10, warm=3)
+    flops = b * (2 * kv - qo) * qo * hq * 2 * d
+    out.append({"workload": "C3: BatchPrefillWithPagedKVCacheWrapper fp8_e4m3 causal qo_len=2048 kv_len=8192 bs=16 "
+                            "head_dim=128 GQA 32/8 page_size=16", "ms": ms, "value": flops / ms / 1e9,
+                "unit": "TFLOP/s", "dtype": "fp8_e4m3",
+                "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 5000.0, "unit": "TFLOP/s",
+                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::batch_prefill_fp8_kernel"}})
+    del cache, q, o, w, ws
+    # C4: 8 experts, M=4096 per expert, N=14336, K=4096, 128-wide block scales
+    G, m, n, k = 8, 4096, 14336, 4096
+    a = torch.randn(G * m, k, device=device, generator=g).to(torch.float8_e4m3fn)
+    bm = (torch.randn(G, n, k, device=device, generator=g) / k ** 0.5).to(torch.float8_e4m3fn)
+    sa = torch.rand(k // 128, G * m, device=device, generator=g) + 0.5
+    sb = torch.rand(G, k // 128, n // 128, device=device, generator=g) + 0.5
+    m_indptr = (torch.arange(G + 1, dtype=torch.int32) * m).to(device)
+    dout = torch.empty(G * m, n, device=device, dtype=torch.bfloat16)
+    ms = _time_ms(lambda: flashinfer.group_gemm_fp8_nt_groupwise(a, bm, sa, sb, m_indptr, out=dout), iters=10, warm=3)
+    flops = 2 * G * m * n * k
+    out.append({"workload": "C4: group_gemm_fp8_nt_groupwise 8 experts M=4096 N=14336 K=4096 block=128", "ms": ms,
+                "value": flops / ms / 1e9, "unit": "TFLOP/s", "dtype": "fp8_e4m3",
+                "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 5000.0, "unit": "TFLOP/s",
+                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::group_gemm_fp8_kernel"}})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +163,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--no-permute", action="store_true", help="arange page table instead of a random permutation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 side measurements (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,6 +264,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+        if world == 1 and not args.no_secondary:
+            del cache, q, out
+            torch.cuda.empty_cache()
+            try:
+                line["secondary"] = secondary_workloads(device)
+            except Exception as exc:  # the headline line must survive a failure of the side measurements
+                line["secondary"] = {"error": repr(exc)}
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
