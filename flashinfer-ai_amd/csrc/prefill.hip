@@ -15,7 +15,7 @@ typedef hipError_t (*prefill_launch_fn)(const PrefillKernelParams&, int, hipStre
 
 #define FI_PF_DECL(T, K, Q, D) \
   hipError_t prefill_launch_##T##_##K##_##Q##_##D(const PrefillKernelParams&, int, hipStream_t);
-#define FI_PF_DECL_D(T, K, Q) FI_PF_DECL(T, K, Q, 64) FI_PF_DECL(T, K, Q, 128)
+#define FI_PF_DECL_D(T, K, Q) FI_PF_DECL(T, K, Q, 64) FI_PF_DECL(T, K, Q, 128) FI_PF_DECL(T, K, Q, 256)
 // 16-bit q: kv of the same type, or fp8 kv upcast on the fly (ref: prefill.cuh:637-647, 993-1004)
 FI_PF_DECL_D(0, 0, 0) FI_PF_DECL_D(0, 2, 0) FI_PF_DECL_D(0, 3, 0)
 FI_PF_DECL_D(1, 1, 1) FI_PF_DECL_D(1, 2, 1) FI_PF_DECL_D(1, 3, 1)
@@ -44,6 +44,7 @@ static prefill_launch_fn find_prefill(int t16, int kvs, int qs, int d) {
   if (t16 == T && kvs == K && qs == Q) {                      \
     if (d == 64) return prefill_launch_##T##_##K##_##Q##_64;  \
     if (d == 128) return prefill_launch_##T##_##K##_##Q##_128; \
+    if (d == 256) return prefill_launch_##T##_##K##_##Q##_256; \
     return nullptr;                                           \
   }
   FI_TRY(0, 0, 0) FI_TRY(0, 2, 0) FI_TRY(0, 3, 0)
@@ -78,8 +79,8 @@ extern "C" FI_API int fi_batch_prefill_plan(
              "batch_prefill_plan: num_qo_heads (%d) must be a multiple of num_kv_heads (%d)",
              num_qo_heads, num_kv_heads);
   FI_REQUIRE(head_dim_qk == head_dim_vo, "batch_prefill_plan: head_dim_qk != head_dim_vo unsupported");
-  FI_REQUIRE(head_dim_qk == 64 || head_dim_qk == 128,
-             "batch_prefill_plan: unsupported head_dim %d (64/128)", head_dim_qk);
+  FI_REQUIRE(head_dim_qk == 64 || head_dim_qk == 128 || head_dim_qk == 256,
+             "batch_prefill_plan: unsupported head_dim %d (64/128/256)", head_dim_qk);
   FI_REQUIRE(qo_indptr_h[0] == 0, "batch_prefill_plan: qo_indptr[0] must be 0");
   const int group = num_qo_heads / num_kv_heads;
 

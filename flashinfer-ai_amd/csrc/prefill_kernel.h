@@ -159,7 +159,8 @@ __device__ __forceinline__ float round_through_e4m3(float x) {
 // T16: MFMA compute type; KVS: K/V storage dtype; QS: Q storage dtype; D: head_dim (64 / 128)
 // GENERAL: ALiBi / logits soft cap compiled in (kept out of the common instantiation's hot loop)
 template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL>
-__global__ void __launch_bounds__(kPrefillThreads, 2)
+// head_dim 256 keeps 128 accumulator + 64 query-fragment registers per lane: one wave per SIMD (512 registers)
+__global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     batch_prefill_kernel(const PrefillKernelParams p) {
   using M = MfmaType<T16>;
   using frag_t = typename M::frag;
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2)
   constexpr int KSTEPS = D / 16;          // MFMA k-steps over head_dim
   constexpr int DBLK = D / 32;            // 32-row blocks of O^T
   constexpr int TILE_BYTES = kTileKV * ROWB;
-  static_assert(D == 64 || D == 128, "head_dim 64 / 128");
+  static_assert(D == 64 || D == 128 || D == 256, "head_dim 64 / 128 / 256");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // layout: [stage][K tile | V tile]

@@ -332,3 +332,29 @@ def test_batch_prefill_split_kv_fp8_native_and_rows_without_keys():
     assert w._plan_info[14] == 0
     assert torch.all(o[:100] == 0) and torch.all(lse[:100].cpu() == R.NEG_INF_SENTINEL)
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("causal", [False, True])
+def test_prefill_head_dim_256(dtype, causal):
+    """head_dim 256 (ref: HEAD_DIM dispatch utils.cuh:175-202; e.g. gemma-style heads) -- batch + single."""
+    import flashinfer
+
+    hq, hkv, d, ps = 4, 2, 256, 16
+    kv_lens, qo_lens = [130, 700, 1], [70, 256, 1]
+    torch.manual_seed(77)
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, ps, hkv, d, dtype, "NHD", seed=78)
+    q = torch.randn(sum(qo_lens), hq, d).to(dtype)
+    o, lse, qo_indptr = run_batch_prefill(q, qo_lens, cache, "NHD", indptr, indices, last, hq, hkv, d, ps,
+                                          causal=causal)
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last,
+                                         causal=causal)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), **ptol(dtype))
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    k, v = torch.randn(300, hkv, d).to(dtype), torch.randn(300, hkv, d).to(dtype)
+    qs = torch.randn(200, hq, d).to(dtype)
+    os_, lses = flashinfer.single_prefill_with_kv_cache(qs.to(DEV), k.to(DEV), v.to(DEV), causal=causal,
+                                                        pos_encoding_mode="ROPE_LLAMA", return_lse=True)
+    os_ref, lses_ref = R.attention_ref(qs.float(), k.float(), v.float(), causal=causal, pos_encoding_mode="ROPE_LLAMA")
+    torch.testing.assert_close(os_.float().cpu(), os_ref.float(), **ptol(dtype))
+    torch.testing.assert_close(lses.cpu(), lses_ref.float(), rtol=2e-3, atol=2e-3)
