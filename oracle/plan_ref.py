@@ -73,3 +73,58 @@ def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, pag
     return dict(split_kv=split, kv_chunk_size=chunk_pages * page_size, padded_batch_size=padded,
                 num_work=len(request_indices), request_indices=request_indices,
                 kv_tile_indices=kv_tile_indices, o_indptr=o_indptr)
+
+
+def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int, num_kv_heads: int,
+                     causal: bool = False, enable_cuda_graph: bool = False, total_num_rows: int = None,
+                     fixed_split_size: int = -1, disable_split_kv: bool = False, num_cus: int = 256,
+                     tile_q: int = 128, tile_kv: int = 64):
+    """Work list of the prefill planner (flashinfer-ai_amd/csrc/prefill.hip), restating the reference's
+      PrefillBinarySearchKVChunkSize   scheduler.cuh:101-130
+      PrefillSplitQOKVIndptr           scheduler.cuh:495-614   (packed_qo_len = qo_len * G, merge_indptr)
+      max_batch_size_if_split = max_grid / num_kv_heads        scheduler.cuh:716-718
+    with the build's constants: a fixed 128-row q tile, chunk sizes in units of one 64-row kv tile (>= 128
+    tokens), max_grid = 2 workgroups x CUs, requests ordered by kv length descending and -- under a causal
+    mask -- the later (heavier) q tiles first."""
+    batch = len(kv_lens)
+    group = num_qo_heads // num_kv_heads
+    q_tiles = [ceil_div((qo_indptr[b + 1] - qo_indptr[b]) * group, tile_q) for b in range(batch)]
+    kv = [max(k, 1) for k in kv_lens]
+    max_kv = max(kv + [1])
+    max_items = max(num_cus * 2 // num_kv_heads, 1)
+    if total_num_rows is None:
+        total_num_rows = qo_indptr[-1]
+    chunk = ceil_div(max_kv, tile_kv) * tile_kv
+    split = False
+    if not disable_split_kv and batch > 0:
+        if fixed_split_size > 0:
+            chunk = ceil_div(fixed_split_size, tile_kv) * tile_kv
+        else:
+            low, high = 128 // tile_kv, ceil_div(max_kv, tile_kv)
+            while low < high:
+                mid = (low + high) // 2
+                if sum(q_tiles[b] * ceil_div(kv[b], mid * tile_kv) for b in range(batch)) > max_items:
+                    low = mid + 1
+                else:
+                    high = mid
+            chunk = max(low, 128 // tile_kv) * tile_kv
+        split = chunk < max_kv or enable_cuda_graph
+    order = sorted(range(batch), key=lambda b: -kv_lens[b])  # stable
+    req, qt, kt = [], [], []
+    for b in order:
+        nchunks = ceil_div(kv[b], chunk) if split else 1
+        for t in range(q_tiles[b]):
+            for c in range(nchunks):
+                req.append(b)
+                qt.append(q_tiles[b] - 1 - t if causal else t)
+                kt.append(c)
+    merge_indptr = [0]
+    if split:
+        for b in range(batch):
+            for _ in range(qo_indptr[b + 1] - qo_indptr[b]):
+                merge_indptr.append(merge_indptr[-1] + ceil_div(kv[b], chunk))
+    padded = len(req)
+    if enable_cuda_graph:
+        padded = max(padded, max_items, ceil_div(total_num_rows * group, tile_q) + max(batch, 1) - 1)
+    return dict(split_kv=split, kv_chunk_size=chunk, request_indices=req, qo_tile_indices=qt,
+                kv_tile_indices=kt, merge_indptr=merge_indptr, padded_batch_size=padded, num_work=len(req))

@@ -99,3 +99,68 @@ def test_workspace_too_small_is_an_error(fi_lib):
     rc = fi_lib.fi_batch_decode_plan(None, 1024, None, pinned, 4096, indptr, 1, 32, 8, 16, 0, 128, 1, 1,
                                      2048, info, None)
     assert rc != 0 and b"workspace too small" in fi_lib.fi_last_error()
+
+
+# ---- prefill planner (split-KV work list) -------------------------------------------------------------
+def run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, causal=False, cuda_graph=False, fixed=-1, disable=False,
+                     page_size=16, float_bytes=1 << 32):
+    from flashinfer import _lib
+
+    n = len(kv_lens)
+    pinned = (C.c_char * (8 << 20))()
+    qo = (C.c_int32 * (n + 1))(*qo_indptr)
+    kvp = [0]
+    for k in kv_lens:
+        kvp.append(kvp[-1] + -(-k // page_size))
+    kvi = (C.c_int32 * (n + 1))(*kvp)
+    kvl = (C.c_int32 * max(n, 1))(*kv_lens)
+    info = (C.c_int64 * _lib.FI_PREFILL_PLAN_INFO_LEN)()
+    rc = fi_lib.fi_batch_prefill_plan(None, float_bytes, None, pinned, len(pinned), qo, kvi, kvl, qo_indptr[-1], n,
+                                      hq, hkv, page_size, int(cuda_graph), 128, 128, int(causal), -1, fixed,
+                                      int(disable), info, None)
+    assert rc == 0, fi_lib.fi_last_error()
+    info = list(info)
+    raw = np.frombuffer(pinned, dtype=np.uint8)
+
+    def i32(off, count):
+        return raw[off: off + 4 * count].view(np.int32).tolist()
+
+    nwork = info[12]
+    out = dict(split_kv=bool(info[14]), kv_chunk_size=info[9], padded_batch_size=info[0], num_work=nwork,
+               request_indices=i32(info[4], nwork), qo_tile_indices=i32(info[5], nwork),
+               kv_tile_indices=i32(info[6], nwork), padding=i32(info[4], info[0])[nwork:])
+    out["merge_indptr"] = i32(info[7], info[1] + 1) if out["split_kv"] else [0]
+    return out
+
+
+PREFILL_CASES = [
+    # (qo_indptr, kv_lens, hq, hkv)
+    ([0, 2048 * 1], [8192], 32, 8),                                   # one C3 request: 64 q tiles, no split
+    ([0, 128], [32768], 32, 8),                                       # append: 4 q tiles -> kv split
+    ([0, 5, 205, 206], [3000, 4097, 130], 8, 2),
+    ([0, 16, 32, 48, 64], [16384] * 4, 32, 8),
+    ([0, 0, 7], [0, 1], 4, 4),                                        # empty request / single key
+    ([0, 300], [300], 28, 4),
+]
+
+
+@pytest.mark.parametrize("case", PREFILL_CASES)
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("mode", ["auto", "graph", "fixed", "disabled"])
+def test_prefill_planner_matches_oracle(fi_lib, monkeypatch, case, causal, mode):
+    from oracle.plan_ref import prefill_plan_ref
+
+    monkeypatch.setenv("FI_NUM_CUS", "256")
+    qo_indptr, kv_lens, hq, hkv = case
+    kw = dict(cuda_graph=mode == "graph", fixed=512 if mode == "fixed" else -1, disable=mode == "disabled")
+    got = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, causal=causal, **kw)
+    exp = prefill_plan_ref(qo_indptr, kv_lens, hq, hkv, causal=causal, enable_cuda_graph=kw["cuda_graph"],
+                           fixed_split_size=kw["fixed"], disable_split_kv=kw["disable"])
+    for key in ("split_kv", "kv_chunk_size", "num_work", "request_indices", "qo_tile_indices", "kv_tile_indices",
+                "padded_batch_size", "merge_indptr"):
+        assert got[key] == exp[key], key
+    assert all(r == -1 for r in got["padding"])
+    # every (request, q tile, kv chunk) exactly once; chunks cover the kv range
+    assert len(set(zip(got["request_indices"], got["qo_tile_indices"], got["kv_tile_indices"]))) == got["num_work"]
+    if got["split_kv"]:
+        assert got["kv_chunk_size"] % 64 == 0 and got["kv_chunk_size"] >= 128
