@@ -198,11 +198,23 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
           for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
       }
       // ---- O^T += V^T P^T (accumulator registers 8s..8s+7 are the B operand of k-step s) ----
+      // The VALU decode kernel (and the reference's CUDA-core decode, decode.cuh:131-144) accumulates p * v
+      // with p in f32.  A bf16 P would lose 8 of its bits, so with bf16 the probabilities go through the
+      // matrix pipe as hi + lo = bf16(p) + bf16(p - bf16(p)) (two MFMAs; the pipe is idle most of the time
+      // in this HBM-bound kernel) and the result does not depend on which decode kernel was selected.
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        u32x4 w;
+        u32x4 w, wl;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack2<T16>(s_acc[8 * s2 + 2 * j], s_acc[8 * s2 + 2 * j + 1]);
+        for (int j = 0; j < 4; ++j) {
+          const float a = s_acc[8 * s2 + 2 * j], b = s_acc[8 * s2 + 2 * j + 1];
+          w[j] = pack2<T16>(a, b);
+          if constexpr (T16 == FI_DTYPE_BF16) {
+            const float ha = __builtin_bit_cast(float, w[j] << 16);
+            const float hb = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+            wl[j] = pack2<T16>(a - ha, b - hb);
+          }
+        }
         const frag_t pfrag = __builtin_bit_cast(frag_t, w);
 #pragma unroll
         for (int db = 0; db < DBLK; ++db) {
@@ -213,6 +225,8 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
           using s16x8 = __attribute__((ext_vector_type(8))) short;
           const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pfrag, o_acc[db]);
+          if constexpr (T16 == FI_DTYPE_BF16)
+            o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, wl), o_acc[db]);
         }
       }
       __builtin_amdgcn_wave_barrier();

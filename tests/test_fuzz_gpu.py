@@ -2,6 +2,7 @@
 page sizes, layouts, variants and plan modes drawn at random (fixed seeds, so failures reproduce).  The grid
 tests elsewhere pin named cases; this one looks for interactions between features (ragged last pages, split
 plans, masks, GQA packing, dtype mixes) the grids do not enumerate."""
+import os
 import random
 
 import pytest
@@ -13,13 +14,14 @@ from test_prefill_gpu import ptol
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+SEEDS = range(int(os.environ.get("FI_FUZZ_SEEDS", "24")))  # FI_FUZZ_SEEDS=300 for a longer hunt
 
 
 def _lens(rng, n, hi):
     return [rng.choice([1, 2, rng.randint(1, 70), rng.randint(1, hi)]) for _ in range(n)]
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_batch_decode(seed):
     import flashinfer
 
@@ -73,7 +75,7 @@ def test_fuzz_batch_decode(seed):
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=lt, atol=lt)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", SEEDS)
 def test_fuzz_batch_prefill(seed):
     import flashinfer
 
