@@ -90,3 +90,29 @@ def test_gemm_errors():
         flashinfer.gemm_fp8_nt_groupwise(a, b, s, s, scale_major_mode="MN")
     with pytest.raises(ValueError):
         flashinfer.gemm_fp8_nt_groupwise(a, a, s, s, scale_major_mode="MN", out_dtype=torch.float32)
+
+
+@pytest.mark.parametrize("ms,n", [([1300, 4, 0, 2300, 520], 400), ([2500], 136), ([128] * 37, 264)])
+def test_group_gemm_exact_many_tiles_banded_order(ms, n):
+    """More m tiles than one band (8) and a ragged last band / last n tile: every (group, m tile, n tile) must
+    be visited exactly once by the banded tile order.  Small integers -> the result is exact."""
+    import flashinfer
+
+    torch.manual_seed(3)
+    g, k = len(ms), 256
+    cum = sum(ms)
+    a = torch.randint(-3, 4, (cum, k)).float()
+    b = torch.randint(-3, 4, (g, n, k)).float()
+    sa = torch.pow(2.0, torch.randint(-1, 2, (k // 128, cum)).float())
+    sb = torch.pow(2.0, torch.randint(-1, 2, (g, k // 128, -(-n // 128))).float())
+    m_indptr = torch.tensor([0] + list(torch.tensor(ms).cumsum(0)), dtype=torch.int32)
+    out = flashinfer.group_gemm_fp8_nt_groupwise(a.to(torch.float8_e4m3fn).to(DEV), b.to(torch.float8_e4m3fn).to(DEV),
+                                                 sa.to(DEV), sb.to(DEV), m_indptr.to(DEV), out_dtype=torch.float16)
+    ref = torch.zeros(cum, n, dtype=torch.float64)
+    for gi in range(g):
+        lo, hi = int(m_indptr[gi]), int(m_indptr[gi + 1])
+        for kb in range(k // 128):
+            part = a[lo:hi, kb * 128:(kb + 1) * 128].double() @ b[gi, :, kb * 128:(kb + 1) * 128].double().T
+            ref[lo:hi] += part * sa[kb, lo:hi, None].double() * sb[gi, kb].double().repeat_interleave(128)[:n][None]
+    assert ref.abs().max() < 60000
+    torch.testing.assert_close(out.float().cpu(), ref.float().half().float(), atol=0, rtol=0)
