@@ -123,6 +123,17 @@ extern "C" FI_API int fi_batch_prefill_plan(
       }
       kv_chunk = std::max<int64_t>(low, 128 / chunk_unit) * chunk_unit;
     }
+    // the partial states must fit the caller's float workspace: grow the chunks until they do (a plan
+    // that cannot split at all is still correct, only less parallel)
+    if (fixed_split_size <= 0) {
+      auto ws_need = [&](int64_t chunk) {
+        int64_t entries = 0;
+        for (int b = 0; b < batch_size; ++b)
+          entries += (int64_t)(qo_indptr_h[b + 1] - qo_indptr_h[b]) * ceil_div<int64_t>(kv_len[b], chunk);
+        return (entries * num_qo_heads * (head_dim_vo + 1) + 64) * (int64_t)sizeof(float);
+      };
+      while (kv_chunk < max_kv_len && ws_need(kv_chunk) > (int64_t)float_ws_bytes) kv_chunk *= 2;
+    }
     split_kv = kv_chunk < max_kv_len;
     // a fixed-shape (graph) launch always takes the split path so that the kernel sequence does not
     // depend on the page table (ref: scheduler.cuh:129)

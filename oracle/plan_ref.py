@@ -78,7 +78,7 @@ def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, pag
 def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int, num_kv_heads: int,
                      causal: bool = False, enable_cuda_graph: bool = False, total_num_rows: int = None,
                      fixed_split_size: int = -1, disable_split_kv: bool = False, num_cus: int = 256,
-                     tile_q: int = 128, tile_kv: int = 64):
+                     tile_q: int = 128, tile_kv: int = 64, float_ws_bytes: int = None, head_dim: int = 128):
     """Work list of the prefill planner (flashinfer-ai_amd/csrc/prefill.hip), restating the reference's
       PrefillBinarySearchKVChunkSize   scheduler.cuh:101-130
       PrefillSplitQOKVIndptr           scheduler.cuh:495-614   (packed_qo_len = qo_len * G, merge_indptr)
@@ -108,6 +108,13 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
                 else:
                     high = mid
             chunk = max(low, 128 // tile_kv) * tile_kv
+        if fixed_split_size <= 0 and float_ws_bytes is not None:
+            # partial states (f32 o + lse per entry and head) must fit the caller's float workspace
+            def need(c):
+                entries = sum((qo_indptr[b + 1] - qo_indptr[b]) * ceil_div(kv[b], c) for b in range(batch))
+                return (entries * num_qo_heads * (head_dim + 1) + 64) * 4
+            while chunk < max_kv and need(chunk) > float_ws_bytes:
+                chunk *= 2
         split = chunk < max_kv or enable_cuda_graph
     order = sorted(range(batch), key=lambda b: -kv_lens[b])  # stable
     req, qt, kt = [], [], []

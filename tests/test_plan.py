@@ -164,3 +164,18 @@ def test_prefill_planner_matches_oracle(fi_lib, monkeypatch, case, causal, mode)
     assert len(set(zip(got["request_indices"], got["qo_tile_indices"], got["kv_tile_indices"]))) == got["num_work"]
     if got["split_kv"]:
         assert got["kv_chunk_size"] % 64 == 0 and got["kv_chunk_size"] >= 128
+
+
+def test_prefill_planner_grows_chunks_to_fit_the_float_workspace(fi_lib, monkeypatch):
+    from oracle.plan_ref import prefill_plan_ref
+
+    monkeypatch.setenv("FI_NUM_CUS", "256")
+    qo_indptr, kv_lens, hq, hkv = [0, 512], [65536], 32, 8
+    roomy = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv)
+    tight_bytes = 24 << 20
+    tight = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, float_bytes=tight_bytes)
+    exp = prefill_plan_ref(qo_indptr, kv_lens, hq, hkv, float_ws_bytes=tight_bytes)
+    assert roomy["split_kv"] and tight["split_kv"] and tight["kv_chunk_size"] > roomy["kv_chunk_size"]
+    assert tight["kv_chunk_size"] == exp["kv_chunk_size"] and tight["kv_tile_indices"] == exp["kv_tile_indices"]
+    entries = tight["merge_indptr"][-1]
+    assert entries * hq * 129 * 4 <= tight_bytes
