@@ -196,6 +196,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Setup, before the W warm-up steps: the first few dozen launches after an idle period run at a lower
+    # clock (power-state ramp, measured ~40 launches); run them here so that a small --warmup does not
+    # leave that transient inside the timed region.  The timed region below is exactly K steps.
+    for _ in range(64):
+        wrapper.run(q, cache, out=out)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         wrapper.run(q, cache, out=out)
     barrier()
