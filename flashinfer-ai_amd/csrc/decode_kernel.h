@@ -18,6 +18,9 @@
 
 namespace fi {
 
+#ifndef FI_DECODE_XCD_REMAP
+#define FI_DECODE_XCD_REMAP 1
+#endif
 constexpr int kDecodeThreads = 256;  // 4 waves; waves are independent
 constexpr int kDecodeWaves = kDecodeThreads / 64;
 constexpr float kMInit = -1.0e30f;  // finite "minus infinity" for the running max
@@ -488,7 +491,17 @@ template <int KV_DT, int HEAD_DIM, int GT, bool ROPE, bool FAST, int NLOAD, bool
 __global__ void __launch_bounds__(kDecodeThreads, 2)
     batch_decode_kernel(const DecodeKernelParams p) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int item = blockIdx.x * kDecodeWaves + wave;
+  // XCD-contiguous logical block id (blocks b and b+8 share an XCD): the workgroups that read the other kv
+  // heads of the same pages run on the same XCD at about the same time
+  int lb;
+  {
+    const int b = blockIdx.x, total = gridDim.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  if (FI_DECODE_XCD_REMAP == 0) lb = blockIdx.x;
+  const int item = lb * kDecodeWaves + wave;
   if (item >= p.num_items) return;
   DecodeWave<KV_DT, HEAD_DIM, GT, ROPE, FAST, NLOAD, NT> w(p);
   w.run(item);

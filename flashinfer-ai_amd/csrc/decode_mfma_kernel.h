@@ -39,7 +39,14 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int item = blockIdx.x * kDecodeWaves + wave;
+  int lb;  // XCD-contiguous logical block id (see decode_kernel.h)
+  {
+    const int b = blockIdx.x, total = gridDim.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    lb = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  }
+  const int item = lb * kDecodeWaves + wave;
   if (item >= p.num_items) return;
   char* const kb = smem[wave];
   char* const vb = kb + TILE_BYTES;
