@@ -169,7 +169,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # FI_BENCH_FORCE_DIST=1 exercises the RCCL code path (init, barrier, all-reduce of the timing) with one rank
+    distributed = world > 1 or os.environ.get("FI_BENCH_FORCE_DIST") == "1"
     if args.gpus != world and distributed:
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     device = torch.device("cuda", local_rank)
