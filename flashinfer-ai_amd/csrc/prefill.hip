@@ -71,7 +71,7 @@ extern "C" FI_API int fi_batch_prefill_plan(
     int32_t page_size, int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
     int32_t causal, int32_t window_left, int32_t fixed_split_size, int32_t disable_split_kv,
     int64_t* plan_info_out, fi_stream_t stream) {
-  (void)float_ws; (void)kv_indptr_h; (void)window_left;
+  (void)float_ws; (void)kv_indptr_h;
   FI_REQUIRE(pinned_int_ws && qo_indptr_h && kv_len_arr_h && plan_info_out,
              "batch_prefill_plan: null argument");
   FI_REQUIRE(batch_size >= 0 && page_size > 0, "batch_prefill_plan: bad batch size / page size");
@@ -94,6 +94,10 @@ extern "C" FI_API int fi_batch_prefill_plan(
     FI_REQUIRE(kv_len_arr_h[b] >= 0, "batch_prefill_plan: negative kv length");
     q_tiles[b] = ceil_div<int64_t>(qo_len * group, kTileQ);
     kv_len[b] = std::max<int64_t>(kv_len_arr_h[b], 1);
+    // sliding window: a q tile only walks the keys from its first row's window start on (the kernel
+    // skips the rest), so chunks are cut from that span (ref: effective_kv_len_arr, scheduler.cuh:561-567)
+    if (window_left >= 0)
+      kv_len[b] = std::min<int64_t>(kv_len[b], (int64_t)window_left + (causal ? kTileQ : qo_len) + kTileKV);
     total_q_tiles += q_tiles[b];
     max_kv_len = std::max(max_kv_len, kv_len[b]);
   }

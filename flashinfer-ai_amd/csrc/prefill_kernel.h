@@ -304,13 +304,20 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
+  // sliding window: keys left of the window of the tile's FIRST query row are visible to no row of the
+  // tile; start at the kv tile that contains that boundary (ref: kv_start_idx, prefill.cuh:1794-1801)
   int kv_begin = 0, kv_chunk = 0;
+  if (p.window_left >= 0) {
+    const int first_pr = min(q_tile * kTileQ, max(packed_len - 1, 0));
+    const int first_qo = (int)fast_div((uint32_t)first_pr, p.group_div);
+    kv_begin = max(kv_len - qo_len + first_qo - p.window_left, 0) / kTileKV * kTileKV;
+  }
   if (p.kv_tile_indices) {
     kv_chunk = p.kv_tile_indices[work];
-    kv_begin = kv_chunk * p.kv_chunk_size;
+    kv_begin += kv_chunk * p.kv_chunk_size;
     kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
   }
-  const int tile_base = kv_begin / kTileKV;  // chunks start on tile boundaries
+  const int tile_base = kv_begin / kTileKV;  // window starts and chunks sit on tile boundaries
   const int num_tiles = kv_end > kv_begin ? (kv_end - kv_begin + kTileKV - 1) / kTileKV : 0;
   // visible kv index range of this lane's query row (ref: prefill.cuh:782-786, variants.cuh:87-89).  A row
   // that sees no key at all (causal with qo_len > kv_len: q_pos < 0) gets a range no index can fall into.

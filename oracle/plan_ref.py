@@ -78,7 +78,8 @@ def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, pag
 def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int, num_kv_heads: int,
                      causal: bool = False, enable_cuda_graph: bool = False, total_num_rows: int = None,
                      fixed_split_size: int = -1, disable_split_kv: bool = False, num_cus: int = 256,
-                     tile_q: int = 128, tile_kv: int = 64, float_ws_bytes: int = None, head_dim: int = 128):
+                     tile_q: int = 128, tile_kv: int = 64, float_ws_bytes: int = None, head_dim: int = 128,
+                     window_left: int = -1):
     """Work list of the prefill planner (flashinfer-ai_amd/csrc/prefill.hip), restating the reference's
       PrefillBinarySearchKVChunkSize   scheduler.cuh:101-130
       PrefillSplitQOKVIndptr           scheduler.cuh:495-614   (packed_qo_len = qo_len * G, merge_indptr)
@@ -90,6 +91,9 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
     group = num_qo_heads // num_kv_heads
     q_tiles = [ceil_div((qo_indptr[b + 1] - qo_indptr[b]) * group, tile_q) for b in range(batch)]
     kv = [max(k, 1) for k in kv_lens]
+    if window_left >= 0:  # span a q tile walks under a sliding window (ref effective_kv_len_arr, scheduler.cuh:561-567)
+        kv = [min(kv[b], window_left + (tile_q if causal else qo_indptr[b + 1] - qo_indptr[b]) + tile_kv)
+              for b in range(batch)]
     max_kv = max(kv + [1])
     max_items = max(num_cus * 2 // num_kv_heads, 1)
     if total_num_rows is None:

@@ -103,7 +103,7 @@ def test_workspace_too_small_is_an_error(fi_lib):
 
 # ---- prefill planner (split-KV work list) -------------------------------------------------------------
 def run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, causal=False, cuda_graph=False, fixed=-1, disable=False,
-                     page_size=16, float_bytes=1 << 32):
+                     page_size=16, float_bytes=1 << 32, window_left=-1):
     from flashinfer import _lib
 
     n = len(kv_lens)
@@ -116,7 +116,7 @@ def run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, causal=False, cuda_gra
     kvl = (C.c_int32 * max(n, 1))(*kv_lens)
     info = (C.c_int64 * _lib.FI_PREFILL_PLAN_INFO_LEN)()
     rc = fi_lib.fi_batch_prefill_plan(None, float_bytes, None, pinned, len(pinned), qo, kvi, kvl, qo_indptr[-1], n,
-                                      hq, hkv, page_size, int(cuda_graph), 128, 128, int(causal), -1, fixed,
+                                      hq, hkv, page_size, int(cuda_graph), 128, 128, int(causal), window_left, fixed,
                                       int(disable), info, None)
     assert rc == 0, fi_lib.fi_last_error()
     info = list(info)
@@ -179,3 +179,18 @@ def test_prefill_planner_grows_chunks_to_fit_the_float_workspace(fi_lib, monkeyp
     assert tight["kv_chunk_size"] == exp["kv_chunk_size"] and tight["kv_tile_indices"] == exp["kv_tile_indices"]
     entries = tight["merge_indptr"][-1]
     assert entries * hq * 129 * 4 <= tight_bytes
+
+
+@pytest.mark.parametrize("causal", [False, True])
+def test_prefill_planner_sliding_window_uses_the_effective_kv_span(fi_lib, monkeypatch, causal):
+    from oracle.plan_ref import prefill_plan_ref
+
+    monkeypatch.setenv("FI_NUM_CUS", "256")
+    qo_indptr, kv_lens, hq, hkv = [0, 64, 128], [40000, 300], 8, 8
+    got = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, causal=causal, window_left=1000)
+    exp = prefill_plan_ref(qo_indptr, kv_lens, hq, hkv, causal=causal, window_left=1000)
+    full = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, causal=causal)
+    for key in ("split_kv", "kv_chunk_size", "request_indices", "qo_tile_indices", "kv_tile_indices", "merge_indptr"):
+        assert got[key] == exp[key], key
+    # the window shortens the span a q tile walks: smaller chunks than the full-kv plan
+    assert got["kv_chunk_size"] < full["kv_chunk_size"]
