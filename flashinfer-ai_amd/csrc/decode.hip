@@ -132,8 +132,8 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
                                     const int32_t* indptr_h, int32_t batch_size,
                                     int32_t num_qo_heads, int32_t num_kv_heads, int32_t page_size,
                                     int32_t enable_cuda_graph, int32_t head_dim, int32_t q_dtype,
-                                    int32_t kv_dtype, int32_t max_grid_hint, int64_t* plan_info_out,
-                                    fi_stream_t stream) {
+                                    int32_t kv_dtype, int32_t max_grid_hint, int32_t window_left,
+                                    int64_t* plan_info_out, fi_stream_t stream) {
   (void)float_ws;
   FI_REQUIRE(pinned_int_ws && indptr_h && plan_info_out, "batch_decode_plan: null argument");
   FI_REQUIRE(batch_size >= 0 && page_size > 0, "batch_decode_plan: bad batch_size/page_size");
@@ -159,18 +159,26 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
       max_grid_hint > 0 ? (uint32_t)max_grid_hint
                         : (uint32_t)(fi_num_compute_units() * decode_waves_per_cu() * (head_tiles > 1 ? 2 : 1));
 
+  // pages a request's chunks are cut from: all of them, or with a sliding window the ones from the page
+  // holding the earliest key the last token can see (kv_len >= (pages - 1) * page_size + 1)
+  if (window_left < 0) window_left = -1;
+  auto eff_pages = [&](int i) -> int32_t {
+    const int32_t np = indptr_h[i + 1] - indptr_h[i];
+    if (window_left < 0 || np <= 0) return np;
+    const int64_t first = std::max<int64_t>((int64_t)(np - 1) * page_size - window_left, 0) / page_size;
+    return (int32_t)(np - first);
+  };
   // ---- work estimation (ref: scheduler.cuh:183-207) ----
   bool split_kv;
   uint32_t pages_per_chunk, new_batch;
   if ((uint64_t)batch_size * gdy >= max_grid) {
     split_kv = false;
     pages_per_chunk = 1;
-    for (int i = 0; i < batch_size; ++i)
-      pages_per_chunk = std::max<uint32_t>(pages_per_chunk, indptr_h[i + 1] - indptr_h[i]);
+    for (int i = 0; i < batch_size; ++i) pages_per_chunk = std::max<uint32_t>(pages_per_chunk, eff_pages(i));
     new_batch = batch_size;
   } else {
     std::vector<int32_t> num_pages(batch_size);
-    for (int i = 0; i < batch_size; ++i) num_pages[i] = indptr_h[i + 1] - indptr_h[i];
+    for (int i = 0; i < batch_size; ++i) num_pages[i] = eff_pages(i);
     // chunks no shorter than one tile pair: >= 128 tokens (ref uses 128/page_size too)
     const uint32_t min_pages = std::max<uint32_t>(128u / (uint32_t)page_size, 1u);
     partition_pages(max_grid, gdy, num_pages, min_pages, &pages_per_chunk, &new_batch);
@@ -199,7 +207,7 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
   size_t w = 0;
   oind_h[0] = 0;
   for (int b = 0; b < batch_size; ++b) {
-    const uint32_t np = (uint32_t)std::max(indptr_h[b + 1] - indptr_h[b], 1);
+    const uint32_t np = (uint32_t)std::max(eff_pages(b), 1);
     const uint32_t nchunks = split_kv ? ceil_div(np, pages_per_chunk) : 1u;
     for (uint32_t t = 0; t < nchunks; ++t) {
       FI_REQUIRE(w < padded, "batch_decode_plan: work list overflow");
@@ -239,6 +247,7 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
   plan_info_out[FI_DP_NUM_WORK] = (int64_t)w;
   plan_info_out[FI_DP_BATCH_SIZE] = batch_size;
   plan_info_out[FI_DP_INT_BYTES_USED] = (int64_t)ia.used;
+  plan_info_out[FI_DP_WINDOW_LEFT] = window_left;
   plan_info_out[FI_DP_MAGIC] = FI_DECODE_PLAN_MAGIC;
 
   if (int_ws && ia.used)
@@ -340,6 +349,10 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   kp.kv_chunk_size = (int32_t)plan_info[FI_DP_KV_CHUNK_SIZE];
   kp.split_kv = split;
   kp.window_left = a->window_left;
+  // chunks were cut from the window's pages at plan(): the kernel offsets them by the same first page
+  kp.plan_window_left = (int32_t)plan_info[FI_DP_WINDOW_LEFT];
+  FI_REQUIRE(kp.plan_window_left < 0 || kp.plan_window_left == a->window_left,
+             "batch_decode_run: window_left %d differs from the planned %d", a->window_left, kp.plan_window_left);
   kp.q_dtype = a->q_dtype;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
   kp.logits_soft_cap = a->logits_soft_cap > 0.f ? a->logits_soft_cap : 0.f;
@@ -412,6 +425,7 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   kp.kv_stride_h = a->kv_stride_h;
   kp.single_kv_len = a->kv_len;
   kp.window_left = a->window_left;
+  kp.plan_window_left = -1;
   kp.q_dtype = a->q_dtype;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
   kp.logits_soft_cap = a->logits_soft_cap > 0.f ? a->logits_soft_cap : 0.f;

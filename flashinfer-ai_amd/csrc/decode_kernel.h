@@ -55,6 +55,7 @@ struct DecodeKernelParams {
   int32_t split_kv;
   int32_t single_kv_len;  // used when indptr == nullptr
   int32_t window_left;    // < 0: off
+  int32_t plan_window_left;  // window the planner cut the chunks for (< 0: chunks start at token 0)
   int32_t q_dtype;
   int32_t use_alibi;
   float logits_soft_cap;  // 0: off
@@ -303,7 +304,13 @@ struct DecodeWave {
       page_begin = 0;
       kv_len = p.single_kv_len;
     }
-    chunk_start = p.split_kv ? kv_tile * p.kv_chunk_size : 0;
+    // with a planned sliding window the chunks start at the first page that can intersect it
+    int chunk_base = 0;
+    if (p.plan_window_left >= 0 && p.indptr) {
+      const int np = p.indptr[req + 1] - page_begin;
+      chunk_base = np > 0 ? max((np - 1) * p.page_size - p.plan_window_left, 0) / p.page_size * p.page_size : 0;
+    }
+    chunk_start = chunk_base + (p.split_kv ? kv_tile * p.kv_chunk_size : 0);
     chunk_end = p.split_kv ? min(chunk_start + p.kv_chunk_size, kv_len) : kv_len;
     // sliding window (ref: variants.cuh:78-91 with qo_len = 1, qo_idx = 0):
     //   visible iff kv_idx + 1 + window_left >= kv_len

@@ -220,7 +220,7 @@ def lib() -> C.CDLL:
     l.fi_abi_version.restype = C.c_int
     l.fi_num_compute_units.restype = C.c_int
     vp, i32, i64p, sz = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_size_t
-    l.fi_batch_decode_plan.argtypes = [vp, sz, vp, vp, sz, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64p, vp]
+    l.fi_batch_decode_plan.argtypes = [vp, sz, vp, vp, sz, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64p, vp]
     l.fi_batch_decode_run.argtypes = [vp, sz, vp, sz, i64p, i32, C.POINTER(BatchDecodeParams), vp]
     l.fi_single_decode_run.argtypes = [C.POINTER(SingleDecodeParams), vp, sz, vp]
     l.fi_merge_state.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]

@@ -399,6 +399,7 @@ class BatchDecodeWithPagedKVCacheWrapper:
                     _lib.fi_dtype(q_data_type),
                     _lib.fi_dtype(kv_data_type),
                     max_grid_hint,
+                    window_left,
                     plan_info,
                     _lib.current_stream(self.device),
                 ),

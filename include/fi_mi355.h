@@ -106,6 +106,7 @@ enum fi_decode_plan_slot {
   FI_DP_NUM_WORK = 11,      /* valid work items (<= padded) */
   FI_DP_BATCH_SIZE = 12,
   FI_DP_INT_BYTES_USED = 13,
+  FI_DP_WINDOW_LEFT = 14,   /* sliding window the chunks were cut for (-1: none); run() must pass the same */
   FI_DP_MAGIC = 15
 };
 #define FI_DECODE_PLAN_MAGIC 0x4649444543ll /* "FIDEC" */
@@ -113,13 +114,16 @@ enum fi_decode_plan_slot {
 /* Host-side planning.  Writes the work list into `pinned_int_ws` and, when `int_ws` is non-NULL,
  * enqueues ONE host-to-device copy of it on `stream` (ref: scheduler.cuh:488-491).  `int_ws == NULL`
  * plans on the host only (used by CPU tests).  `indptr_h` is the HOST copy of the page indptr.
- * `max_grid_hint` <= 0 lets the library size the grid from the device (CUs x resident waves). */
+ * `max_grid_hint` <= 0 lets the library size the grid from the device (CUs x resident waves).
+ * `window_left` >= 0 (the reference passes it to plan too, csrc/batch_decode.cu:39-79): only the pages that
+ * can intersect the window of the last token are partitioned into chunks; the pages before
+ * max(0, (num_pages - 1) * page_size - window_left) / page_size are never read. */
 FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws,
                          size_t int_ws_bytes, const int32_t* indptr_h, int32_t batch_size,
                          int32_t num_qo_heads, int32_t num_kv_heads, int32_t page_size,
                          int32_t enable_cuda_graph, int32_t head_dim, int32_t q_dtype,
-                         int32_t kv_dtype, int32_t max_grid_hint, int64_t* plan_info_out,
-                         fi_stream_t stream);
+                         int32_t kv_dtype, int32_t max_grid_hint, int32_t window_left,
+                         int64_t* plan_info_out, fi_stream_t stream);
 
 typedef struct fi_batch_decode_params {
   const void* q; /* [batch, num_qo_heads, head_dim], strides below */

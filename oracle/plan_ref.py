@@ -49,11 +49,16 @@ def partition_pages(max_grid: int, gdy: int, num_pages: List[int], min_pages: in
 
 
 def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, page_size: int,
-                    max_grid: int, enable_cuda_graph: bool = False, kv_bytes: int = 2, head_dim: int = 128):
+                    max_grid: int, enable_cuda_graph: bool = False, kv_bytes: int = 2, head_dim: int = 128,
+                    window_left: int = -1):
     batch = len(indptr) - 1
     group = num_qo_heads // num_kv_heads
     gdy = num_kv_heads * head_tiles(group, kv_bytes, head_dim)
     num_pages = [indptr[i + 1] - indptr[i] for i in range(batch)]
+    if window_left >= 0:
+        # only the pages from the one holding the earliest key the last token can see are partitioned
+        # (kv_len >= (pages - 1) * page_size + 1); build-specific, the reference reads and masks them
+        num_pages = [n - max((n - 1) * page_size - window_left, 0) // page_size if n > 0 else n for n in num_pages]
     if batch * gdy >= max_grid:
         split, chunk_pages, new_batch = False, max(num_pages + [1]), batch
     else:

@@ -40,16 +40,16 @@ def test_errors_are_reported_not_thrown(fi_lib):
 
     info = (C.c_int64 * _lib.FI_DECODE_PLAN_INFO_LEN)()
     # null pinned buffer / indptr
-    rc = fi_lib.fi_batch_decode_plan(None, 0, None, None, 0, None, 1, 8, 8, 16, 0, 128, 0, 0, 0, info, None)
+    rc = fi_lib.fi_batch_decode_plan(None, 0, None, None, 0, None, 1, 8, 8, 16, 0, 128, 0, 0, 0, -1, info, None)
     assert rc != 0
     assert b"null" in fi_lib.fi_last_error()
     # num_qo_heads not a multiple of num_kv_heads
     buf = (C.c_char * 4096)()
     indptr = (C.c_int32 * 2)(0, 4)
-    rc = fi_lib.fi_batch_decode_plan(None, 0, None, buf, 4096, indptr, 1, 7, 2, 16, 0, 128, 0, 0, 0, info, None)
+    rc = fi_lib.fi_batch_decode_plan(None, 0, None, buf, 4096, indptr, 1, 7, 2, 16, 0, 128, 0, 0, 0, -1, info, None)
     assert rc != 0 and b"multiple" in fi_lib.fi_last_error()
     # unsupported head_dim
-    rc = fi_lib.fi_batch_decode_plan(None, 0, None, buf, 4096, indptr, 1, 8, 2, 16, 0, 96, 0, 0, 0, info, None)
+    rc = fi_lib.fi_batch_decode_plan(None, 0, None, buf, 4096, indptr, 1, 8, 2, 16, 0, 96, 0, 0, 0, -1, info, None)
     assert rc != 0 and b"unsupported" in fi_lib.fi_last_error()
     # run with a plan_info that is not a plan
     with pytest.raises(RuntimeError, match="plan"):

@@ -10,7 +10,7 @@ from oracle.plan_ref import decode_plan_ref
 
 
 def run_plan(fi_lib, indptr, hq, hkv, page_size, max_grid, cuda_graph=False, head_dim=128,
-             float_bytes=1 << 30):
+             float_bytes=1 << 30, window_left=-1):
     from flashinfer import _lib
 
     n = len(indptr) - 1
@@ -18,7 +18,7 @@ def run_plan(fi_lib, indptr, hq, hkv, page_size, max_grid, cuda_graph=False, hea
     arr = (C.c_int32 * len(indptr))(*indptr)
     info = (C.c_int64 * _lib.FI_DECODE_PLAN_INFO_LEN)()
     rc = fi_lib.fi_batch_decode_plan(None, float_bytes, None, pinned, len(pinned), arr, n, hq, hkv,
-                                     page_size, int(cuda_graph), head_dim, 1, 1, max_grid, info, None)
+                                     page_size, int(cuda_graph), head_dim, 1, 1, max_grid, window_left, info, None)
     assert rc == 0, fi_lib.fi_last_error()
     info = list(info)
     raw = np.frombuffer(pinned, dtype=np.uint8)
@@ -97,7 +97,7 @@ def test_workspace_too_small_is_an_error(fi_lib):
     pinned = (C.c_char * 4096)()
     info = (C.c_int64 * _lib.FI_DECODE_PLAN_INFO_LEN)()
     rc = fi_lib.fi_batch_decode_plan(None, 1024, None, pinned, 4096, indptr, 1, 32, 8, 16, 0, 128, 1, 1,
-                                     2048, info, None)
+                                     2048, -1, info, None)
     assert rc != 0 and b"workspace too small" in fi_lib.fi_last_error()
 
 
@@ -194,3 +194,14 @@ def test_prefill_planner_sliding_window_uses_the_effective_kv_span(fi_lib, monke
         assert got[key] == exp[key], key
     # the window shortens the span a q tile walks: smaller chunks than the full-kv plan
     assert got["kv_chunk_size"] < full["kv_chunk_size"]
+
+
+def test_decode_planner_sliding_window_partitions_only_the_window_pages(fi_lib):
+    indptr = [0, 4096, 4100, 4101]  # 65536, 64 and 16 tokens at page 16
+    got = run_plan(fi_lib, indptr, 32, 8, 16, 2048, window_left=1000)
+    exp = decode_plan_ref(indptr, 32, 8, 16, 2048, window_left=1000)
+    full = run_plan(fi_lib, indptr, 32, 8, 16, 2048)
+    for key in ("split_kv", "kv_chunk_size", "num_work", "request_indices", "kv_tile_indices", "o_indptr"):
+        assert got[key] == exp[key], key
+    assert got["info"][14] == 1000 and full["info"][14] == -1
+    assert got["kv_chunk_size"] < full["kv_chunk_size"]  # 64 window pages, not 4096, are spread over the grid
