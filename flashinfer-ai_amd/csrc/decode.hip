@@ -343,7 +343,7 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   kp.kv_stride_h = kv.stride_h;
   const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim) &&
                         a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
-                        a->window_left < 0 && kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
+                        kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
   if (use_mfma) kp.head_tiles = 1;
   kp.num_items = (int32_t)(padded * kv.num_kv_heads * kp.head_tiles);
   kp.kv_chunk_size = (int32_t)plan_info[FI_DP_KV_CHUNK_SIZE];
@@ -367,9 +367,9 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
     kp.tmp_o = (float*)((char*)float_ws + plan_info[FI_DP_V_OFFSET]);
     kp.tmp_lse = (float*)((char*)float_ws + plan_info[FI_DP_S_OFFSET]);
   }
-  // fast path: scalar page ids, no logits transform, no window (see decode_kernel.h)
+  // fast path: scalar page ids, no logits transform (see decode_kernel.h)
   kp.fast_path = kp.uniform_page && kp.indices && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
-                 kp.window_left < 0 && !getenv("FI_DECODE_FORCE_GENERIC");
+                 !getenv("FI_DECODE_FORCE_GENERIC");
   if (kp.num_items > 0) {
     const int grid = ceil_div(kp.num_items, kDecodeWaves);
     if (use_mfma)
@@ -435,7 +435,7 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
 
   const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim) &&
                         a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
-                        a->window_left < 0 && kp.kv_stride_page < (1ll << 31);
+                        kp.kv_stride_page < (1ll << 31);
   if (use_mfma) kp.head_tiles = 1;
   // split-KV so that the chip is filled (ref: decode.cuh:689-733, kv_len > 256 -> chunks >= 256)
   const int gdy = a->num_kv_heads * kp.head_tiles;

@@ -381,19 +381,28 @@ struct DecodeWave {
     }
 
     // ---- stream the chunk ----
+    // sliding window: start at the tile that holds the window start; only that tile needs the window
+    // mask (everything after it is visible), so it is the one masked tile ahead of the pipelined loop
     int first = chunk_start;
-    if constexpr (!FAST) {
-      if (p.window_left >= 0 && win_start > chunk_start)
-        first = chunk_start + (win_start - chunk_start) / TILE * TILE;
+    bool lead_masked = false;
+    if (p.window_left >= 0 && win_start > chunk_start) {
+      first = chunk_start + (win_start - chunk_start) / TILE * TILE;
+      lead_masked = win_start > first;
+    }
+    int pgA[NLOAD], pgB[NLOAD];
+    Buf A, B;
+    if (lead_masked && first < chunk_end) {
+      fetch_pages<false>(first, pgA);
+      issue_loads<false>(first, pgA, A);
+      if constexpr (ROPE) rope_seed(rope_pos0 + first + r);
+      compute<true>(first, A);
+      first += TILE;
     }
     const int n_tok = chunk_end - first;
     if (n_tok > 0) {
-      const bool all_masked_mode = !FAST && p.window_left >= 0;
       const int ntot = (n_tok + TILE - 1) / TILE;
-      const int nfull = all_masked_mode ? 0 : n_tok / TILE;
+      const int nfull = n_tok / TILE;
       if constexpr (ROPE) rope_seed(rope_pos0 + first + r);
-      int pgA[NLOAD], pgB[NLOAD];
-      Buf A, B;
       int t = 0;
       if (nfull > 0) {
         // Software pipeline over the full tiles: while tile t is consumed from one register buffer,
@@ -424,7 +433,7 @@ struct DecodeWave {
           t += 1;
         }
       }
-      // masked tiles (the partial last tile; every tile when a sliding window is active)
+      // the partial last tile
       for (; t < ntot; ++t) {
         fetch_pages<false>(first + t * TILE, pgA);
         issue_loads<false>(first + t * TILE, pgA, A);

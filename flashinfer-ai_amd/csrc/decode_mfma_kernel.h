@@ -69,8 +69,18 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
   } else {
     kv_len = p.single_kv_len;
   }
-  const int chunk_start = p.split_kv ? kv_tile * p.kv_chunk_size : 0;
+  // sliding window (ref: variants.cuh:78-91 with qo_len = 1): visible iff kv_idx >= kv_len - 1 - window_left.
+  // With a planned window the chunks start at the first page that can intersect it (decode.hip); inside its
+  // chunk the wave starts at the 32-token tile that holds the window start.
+  int chunk_base = 0;
+  if (p.plan_window_left >= 0 && p.indptr) {
+    const int np = p.indptr[req + 1] - page_begin;
+    chunk_base = np > 0 ? max((np - 1) * p.page_size - p.plan_window_left, 0) / p.page_size * p.page_size : 0;
+  }
+  const int win_start = p.window_left >= 0 ? max(0, kv_len - 1 - p.window_left) : 0;
+  int chunk_start = chunk_base + (p.split_kv ? kv_tile * p.kv_chunk_size : 0);
   const int chunk_end = p.split_kv ? min(chunk_start + p.kv_chunk_size, kv_len) : kv_len;
+  if (win_start > chunk_start) chunk_start += (win_start - chunk_start) / kDmTileKV * kDmTileKV;
   const int G = p.group_size;
   const int head = kv_head * G + min(lq, G - 1);
 
@@ -177,11 +187,15 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
         const u32x4 a = *(const u32x4*)(kb + k_rd[ks]);
         s_acc = M::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc);
       }
-      if (tile0 + kDmTileKV > chunk_end) {
-        // tail tile: accumulator register r of lane (q, lh) is kv row 8 (r >> 2) + 4 lh + (r & 3)
-        const int left = chunk_end - tile0 - 4 * lh;
+      if (tile0 + kDmTileKV > chunk_end || tile0 < win_start) {
+        // tail tile / window-start tile: accumulator register r of lane (q, lh) is kv row
+        // 8 (r >> 2) + 4 lh + (r & 3); visible rows are [win_start, chunk_end)
+        const int lo = win_start - tile0 - 4 * lh, hi = chunk_end - tile0 - 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s_acc[r] = ((r & 3) + 8 * (r >> 2) < left) ? s_acc[r] : -INFINITY;
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2);
+          s_acc[r] = (row >= lo && row < hi) ? s_acc[r] : -INFINITY;
+        }
       }
       // ---- online softmax (base 2) ----
       float mx = s_acc[0];
