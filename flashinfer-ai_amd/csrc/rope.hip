@@ -26,6 +26,7 @@ struct RopeParams {
   int64_t qo_stride_n, qo_stride_h, ko_stride_n, ko_stride_h;
   int32_t nnz, num_q_heads, num_k_heads, head_dim, rotary_dim;
   int32_t interleave, dtype;
+  int32_t heads_per_thread;  // heads one thread walks (all of them when there are enough tokens to fill the chip)
   float rope_rcp_scale, rope_rcp_theta, smooth_a, smooth_b;
 };
 
@@ -39,94 +40,111 @@ __device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
   *cs = __builtin_amdgcn_cosf(rev);
 }
 
+// One thread owns one (token, chunk pair) and walks ALL q and k heads of that token: the angles depend on
+// (position, pair index) only, so the 8 sin/cos values (a powf, a range reduction and two transcendental
+// instructions each) are computed once and reused for every head; per head only the loads, the rotation
+// FMAs and the stores remain (measured at 32k tokens, 32 + 8 heads: 1.4 -> 4.4 TB/s of read + write traffic).
+// Small batches split the heads over several threads (heads_per_thread) to keep the chip busy.
 __global__ void __launch_bounds__(kRopeThreads) rope_kernel(const RopeParams p) {
   const int cph = p.head_dim / 8;             // 16-byte chunks per head row
   const int rot_chunks = p.rotary_dim / 8;    // chunks inside the rotary part
   const int pairs = rot_chunks / 2;           // threads that rotate (2 chunks each)
   const int pass = cph - rot_chunks;          // pass-through chunks (only copied when out of place)
-  const int tph = pairs + (pass + 1) / 2;     // threads per head
+  const int tph = pairs + (pass + 1) / 2;     // threads per token
   const int heads = p.num_q_heads + p.num_k_heads;
-  const int64_t total = (int64_t)p.nnz * heads * tph;
+  const int hgroups = (heads + p.heads_per_thread - 1) / p.heads_per_thread;
+  const int64_t total = (int64_t)p.nnz * hgroups * tph;
   for (int64_t it = (int64_t)blockIdx.x * kRopeThreads + threadIdx.x; it < total;
        it += (int64_t)gridDim.x * kRopeThreads) {
     const int t = (int)(it % tph);
-    const int64_t r = it / tph;
-    const int h = (int)(r % heads);
-    const int tok = (int)(r / heads);
-    const bool is_q = h < p.num_q_heads;
-    const int hh = is_q ? h : h - p.num_q_heads;
-    const uint16_t* src = (const uint16_t*)(is_q ? p.q : p.k) +
-                          (int64_t)tok * (is_q ? p.q_stride_n : p.k_stride_n) +
-                          (int64_t)hh * (is_q ? p.q_stride_h : p.k_stride_h);
-    uint16_t* dst = (uint16_t*)(is_q ? p.q_out : p.k_out) +
-                    (int64_t)tok * (is_q ? p.qo_stride_n : p.ko_stride_n) +
-                    (int64_t)hh * (is_q ? p.qo_stride_h : p.ko_stride_h);
+    const int64_t r_ = it / tph;
+    const int hg = (int)(r_ % hgroups);
+    const int tok = (int)(r_ / hgroups);
+    const int h_begin = hg * p.heads_per_thread, h_end = min(heads, h_begin + p.heads_per_thread);
+    const uint16_t* const q_src = (const uint16_t*)p.q + (int64_t)tok * p.q_stride_n;
+    const uint16_t* const k_src = (const uint16_t*)p.k + (int64_t)tok * p.k_stride_n;
+    uint16_t* const q_dst = (uint16_t*)p.q_out + (int64_t)tok * p.qo_stride_n;
+    uint16_t* const k_dst = (uint16_t*)p.k_out + (int64_t)tok * p.ko_stride_n;
     if (t >= pairs) {  // pass-through part
-      if (src != dst) {
-        const int c0 = rot_chunks + 2 * (t - pairs);
+      const int c0 = rot_chunks + 2 * (t - pairs);
+      for (int h = h_begin; h < h_end; ++h) {
+        const bool is_q = h < p.num_q_heads;
+        const int hh = is_q ? h : h - p.num_q_heads;
+        const uint16_t* src = (is_q ? q_src : k_src) + (int64_t)hh * (is_q ? p.q_stride_h : p.k_stride_h);
+        uint16_t* dst = (is_q ? q_dst : k_dst) + (int64_t)hh * (is_q ? p.qo_stride_h : p.ko_stride_h);
+        if (src == dst) continue;
         *(u32x4*)(dst + 8 * c0) = *(const u32x4*)(src + 8 * c0);
         if (c0 + 1 < cph) *(u32x4*)(dst + 8 * (c0 + 1)) = *(const u32x4*)(src + 8 * (c0 + 1));
       }
       continue;
     }
-    // chunks a, b and the pair index (0 .. rotary_dim/2) of their first pair
+    // chunks a, b; pair index of element j: interleaved -> elements (2m, 2m+1) of the 16-element span are
+    // pair 8t + m; otherwise element j of chunk a pairs with element j of chunk b: pair 8t + j
     const int ca = p.interleave ? 2 * t : t;
     const int cb = p.interleave ? 2 * t + 1 : t + pairs;
-    const u32x4 ra = *(const u32x4*)(src + 8 * ca);
-    const u32x4 rb = *(const u32x4*)(src + 8 * cb);
-    float xa[8], xb[8];
-    if (p.dtype == FI_DTYPE_BF16) {
-      KVTraits<FI_DTYPE_BF16>::unpack(ra, xa);
-      KVTraits<FI_DTYPE_BF16>::unpack(rb, xb);
-    } else {
-      KVTraits<FI_DTYPE_F16>::unpack(ra, xa);
-      KVTraits<FI_DTYPE_F16>::unpack(rb, xb);
-    }
     const int pos = p.pos_ids[tok];
-    float ya[8], yb[8];
+    float sn[8], cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      // pair index: interleaved -> elements (2m, 2m+1) of the 16-element span are pair 8t + m;
-      // otherwise element j of chunk a pairs with element j of chunk b: pair 8t + j
       const int m = 8 * t + j;
-      float sn, cs;
       if (p.cos_sin_cache) {
         const float* row = p.cos_sin_cache + (int64_t)pos * p.rotary_dim;
-        cs = row[m];
-        sn = row[p.rotary_dim / 2 + m];
+        cs[j] = row[m];
+        sn[j] = row[p.rotary_dim / 2 + m];
       } else {
         float freq = __powf(p.rope_rcp_theta, (float)(2 * m) / (float)p.rotary_dim);
         float smooth = fminf(fmaxf(freq * p.smooth_a + p.smooth_b, 0.f), 1.f);
         freq = (1.f - smooth) * (freq * p.rope_rcp_scale) + smooth * freq;
-        fast_sincos((float)pos * freq, &sn, &cs);
-      }
-      float x0, x1;
-      if (p.interleave) {
-        // pair m lives at span elements 2j, 2j+1 (span = chunk a then chunk b)
-        x0 = (j < 4) ? xa[2 * j] : xb[2 * j - 8];
-        x1 = (j < 4) ? xa[2 * j + 1] : xb[2 * j - 7];
-      } else {
-        x0 = xa[j];
-        x1 = xb[j];
-      }
-      const float y0 = x0 * cs - x1 * sn;  // ref: pos_enc.cuh:93-96, 143-145
-      const float y1 = x1 * cs + x0 * sn;
-      if (p.interleave) {
-        if (j < 4) { ya[2 * j] = y0; ya[2 * j + 1] = y1; }
-        else { yb[2 * j - 8] = y0; yb[2 * j - 7] = y1; }
-      } else {
-        ya[j] = y0;
-        yb[j] = y1;
+        fast_sincos((float)pos * freq, &sn[j], &cs[j]);
       }
     }
-    u32x4 wa, wb;
+#pragma unroll 4
+    for (int h = h_begin; h < h_end; ++h) {
+      const bool is_q = h < p.num_q_heads;
+      const int hh = is_q ? h : h - p.num_q_heads;
+      const uint16_t* src = (is_q ? q_src : k_src) + (int64_t)hh * (is_q ? p.q_stride_h : p.k_stride_h);
+      uint16_t* dst = (is_q ? q_dst : k_dst) + (int64_t)hh * (is_q ? p.qo_stride_h : p.ko_stride_h);
+      const u32x4 ra = *(const u32x4*)(src + 8 * ca);
+      const u32x4 rb = *(const u32x4*)(src + 8 * cb);
+      float xa[8], xb[8];
+      if (p.dtype == FI_DTYPE_BF16) {
+        KVTraits<FI_DTYPE_BF16>::unpack(ra, xa);
+        KVTraits<FI_DTYPE_BF16>::unpack(rb, xb);
+      } else {
+        KVTraits<FI_DTYPE_F16>::unpack(ra, xa);
+        KVTraits<FI_DTYPE_F16>::unpack(rb, xb);
+      }
+      float ya[8], yb[8];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      wa[j] = (uint32_t)f32_to_16bit(ya[2 * j], p.dtype) | ((uint32_t)f32_to_16bit(ya[2 * j + 1], p.dtype) << 16);
-      wb[j] = (uint32_t)f32_to_16bit(yb[2 * j], p.dtype) | ((uint32_t)f32_to_16bit(yb[2 * j + 1], p.dtype) << 16);
+      for (int j = 0; j < 8; ++j) {
+        float x0, x1;
+        if (p.interleave) {
+          // pair m lives at span elements 2j, 2j+1 (span = chunk a then chunk b)
+          x0 = (j < 4) ? xa[2 * j] : xb[2 * j - 8];
+          x1 = (j < 4) ? xa[2 * j + 1] : xb[2 * j - 7];
+        } else {
+          x0 = xa[j];
+          x1 = xb[j];
+        }
+        const float y0 = x0 * cs[j] - x1 * sn[j];  // ref: pos_enc.cuh:93-96, 143-145
+        const float y1 = x1 * cs[j] + x0 * sn[j];
+        if (p.interleave) {
+          if (j < 4) { ya[2 * j] = y0; ya[2 * j + 1] = y1; }
+          else { yb[2 * j - 8] = y0; yb[2 * j - 7] = y1; }
+        } else {
+          ya[j] = y0;
+          yb[j] = y1;
+        }
+      }
+      u32x4 wa, wb;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        wa[j] = (uint32_t)f32_to_16bit(ya[2 * j], p.dtype) | ((uint32_t)f32_to_16bit(ya[2 * j + 1], p.dtype) << 16);
+        wb[j] = (uint32_t)f32_to_16bit(yb[2 * j], p.dtype) | ((uint32_t)f32_to_16bit(yb[2 * j + 1], p.dtype) << 16);
+      }
+      *(u32x4*)(dst + 8 * ca) = wa;
+      *(u32x4*)(dst + 8 * cb) = wb;
     }
-    *(u32x4*)(dst + 8 * ca) = wa;
-    *(u32x4*)(dst + 8 * cb) = wb;
   }
 }
 
@@ -177,7 +195,12 @@ extern "C" FI_API int fi_apply_rope_pos_ids(const fi_rope_params_t* a, fi_stream
   p.smooth_a = a->smooth_a; p.smooth_b = a->smooth_b;
   const int cph = a->head_dim / 8, rot_chunks = a->rotary_dim / 8;
   const int tph = rot_chunks / 2 + (cph - rot_chunks + 1) / 2;
-  const int64_t total = (int64_t)a->nnz * (a->num_q_heads + a->num_k_heads) * tph;
+  // one thread per (token, head group, chunk pair): all heads per thread once the tokens alone give
+  // >= 64K threads, fewer heads per thread (more threads) for small batches
+  const int heads = a->num_q_heads + a->num_k_heads;
+  const int64_t base_threads = (int64_t)a->nnz * tph;
+  p.heads_per_thread = (int)std::min<int64_t>(heads, std::max<int64_t>(1, heads * base_threads / 65536));
+  const int64_t total = base_threads * ((heads + p.heads_per_thread - 1) / p.heads_per_thread);
   const int grid = (int)std::min<int64_t>((total + kRopeThreads - 1) / kRopeThreads, 256 * 16);
   rope_kernel<<<dim3(grid), dim3(kRopeThreads), 0, (hipStream_t)stream>>>(p);
   FI_HIP_CALL(hipGetLastError());
