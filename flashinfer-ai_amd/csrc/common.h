@@ -95,6 +95,17 @@ __device__ __attribute__((noinline)) static void sincos_ool(float x, float* sn, 
   sincosf(x, sn, cs);
 }
 
+// sin / cos of an angle in radians: x = k * 2pi + y with |y| <= pi (two-term Cody-Waite reduction), then
+// the hardware v_sin / v_cos on y / 2pi.  Absolute error ~1e-6 for |x| up to ~1e5 (RoPE angles).
+__device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
+  const float k = rintf(x * 0.15915494309189535f);
+  float y = __builtin_fmaf(-k, 6.2831854820251465f, x);       // 2pi high part (float)
+  y = __builtin_fmaf(-k, -1.7484555e-07f, y);                 // 2pi - float(2pi)
+  const float rev = y * 0.15915494309189535f;
+  *sn = __builtin_amdgcn_sinf(rev);
+  *cs = __builtin_amdgcn_cosf(rev);
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

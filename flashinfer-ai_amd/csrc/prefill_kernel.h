@@ -372,6 +372,15 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       }
     }
   };
+  // fused RoPE: frequencies of the 8 dims of this thread's chunk (dim i and i + D/2 share one)
+  float rope_freq[8];
+  if constexpr (ROPE) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = (st_ch * 8 + e) % (D / 2);
+      rope_freq[e] = p.rope_rcp_scale * __powf(p.rope_rcp_theta, (float)(2 * i) / (float)D);
+    }
+  }
   // swizzles (see header comment): K image for ds_read_b128, V image for ds_read_b64_tr_b16
   auto k_lds_off = [&](int row, int ch) -> int {
     const int sw = (CPR >= 16) ? (row & 15) : ((row >> 1) & 7);
@@ -391,22 +400,29 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       if constexpr (KV_FP8) kw = fp8x8_to_16<T16, KVS>(u32x2{st.r[ps][0], st.r[ps][1]});
       else kw = st.r[ps];
       if constexpr (ROPE) {
-        // rotate K at its absolute position; the partner chunk sits CPR/2 lanes away
+        // rotate K at its absolute position (ref: k_smem_inplace_apply_rotary, prefill.cuh:536-612).  The
+        // partner chunk (dims +- D/2) sits CPR/2 lanes away: its packed registers are fetched with four
+        // cross-lane moves; sin / cos come from the hardware functions on a reduced angle, the eight
+        // frequencies of this thread's chunk are loop invariants (rope_freq).
         const int kvi = tile * kTileKV + row;
+        u32x4 pw;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t mine = kw[w];  // scalar copy first: bit_cast of a vector-element lvalue reads element 0
+          pw[w] = __builtin_bit_cast(uint32_t, lane_xor<CPR / 2>(__builtin_bit_cast(float, mine)));
+        }
+        const float sgn = (st_ch < CPR / 2) ? -1.f : 1.f;
         u32x4 outw;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           uint32_t res = 0;
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const int i = st_ch * 8 + 2 * w + e;
-            const float freq = p.rope_rcp_scale *
-                               __powf(p.rope_rcp_theta, (float)(2 * (i % (D / 2))) / (float)D);
             float sn, cs;
-            sincos_ool((float)kvi * freq, &sn, &cs);
+            fast_sincos((float)kvi * rope_freq[2 * w + e], &sn, &cs);
             const float x = M::to_f32((uint16_t)(kw[w] >> (16 * e)));
-            const float partner = __shfl_xor(x, CPR / 2, 64);
-            const float y = x * cs + ((st_ch < CPR / 2) ? -partner : partner) * sn;
+            const float partner = M::to_f32((uint16_t)(pw[w] >> (16 * e)));
+            const float y = __builtin_fmaf(sgn * partner, sn, x * cs);
             res |= (uint32_t)M::from_f32(y) << (16 * e);
           }
           outw[w] = res;

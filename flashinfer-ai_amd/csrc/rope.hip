@@ -30,16 +30,6 @@ struct RopeParams {
   float rope_rcp_scale, rope_rcp_theta, smooth_a, smooth_b;
 };
 
-__device__ __forceinline__ void fast_sincos(float x, float* sn, float* cs) {
-  // x = k * 2pi + y, |y| <= pi (two-term reduction), then the hardware functions on y / 2pi
-  const float k = rintf(x * 0.15915494309189535f);
-  float y = __builtin_fmaf(-k, 6.2831854820251465f, x);       // 2pi high part (float)
-  y = __builtin_fmaf(-k, -1.7484555e-07f, y);                 // 2pi - float(2pi)
-  const float rev = y * 0.15915494309189535f;
-  *sn = __builtin_amdgcn_sinf(rev);
-  *cs = __builtin_amdgcn_cosf(rev);
-}
-
 // One thread owns one (token, chunk pair) and walks ALL q and k heads of that token: the angles depend on
 // (position, pair index) only, so the 8 sin/cos values (a powf, a range reduction and two transcendental
 // instructions each) are computed once and reused for every head; per head only the loads, the rotation
