@@ -295,6 +295,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   const uint8_t* const mask_bits =
       (GENERAL && p.custom_mask) ? p.custom_mask + (p.mask_indptr ? p.mask_indptr[req] : 0) : nullptr;
   const uint64_t mask_row = (uint64_t)qo_idx * (uint64_t)kv_len;
+  const uint64_t mask_bytes = ((uint64_t)qo_len * (uint64_t)kv_len + 7) >> 3;  // of this request
 
   // ---- kv range of this workgroup ----
   int kv_end = kv_len;
@@ -551,6 +552,23 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
                              (p.causal && tile0 + kTileKV - 1 > min_qpos_wave) ||
                              (p.window_left >= 0);
       if constexpr (GENERAL) {
+        // custom mask: the 64 bits of this lane's query row for the tile's keys (bit qo_idx * kv_len + kv_idx,
+        // little-endian; ref: variants.cuh:80-86) are gathered from 9 bytes into two 32-bit windows, one
+        // per 32-key block.  Byte indices are clamped to the request's mask: bits past its end belong to no
+        // visible key.
+        uint32_t mask_win[2] = {~0u, ~0u};
+        if (mask_bits) {
+          const uint64_t bit0 = mask_row + (uint64_t)tile0;
+          const uint64_t byte0 = bit0 >> 3;
+          const uint32_t sh = (uint32_t)(bit0 & 7);
+          uint32_t bytes[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) bytes[i] = mask_bits[min(byte0 + i, mask_bytes - 1)];
+          const uint32_t w0 = bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | (bytes[3] << 24);
+          const uint32_t w1 = bytes[4] | (bytes[5] << 8) | (bytes[6] << 16) | (bytes[7] << 24);
+          mask_win[0] = __builtin_amdgcn_alignbit(w1, w0, sh);       // ({w1, w0} >> sh) & 0xffffffff
+          mask_win[1] = __builtin_amdgcn_alignbit(bytes[8], w1, sh);
+        }
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
@@ -562,10 +580,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
             if (p.use_alibi) lg += slope * (float)(kv_idx - qo_idx);
             if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg * inv_cap);
             lg *= inv_qk_scale;
-            if (mask_bits) {  // ref: variants.cuh:80-86 -- bit qo_idx * kv_len + kv_idx of the request's mask
-              const uint64_t off = mask_row + (uint64_t)min(kv_idx, kv_len - 1);
-              lg = ((mask_bits[off >> 3] >> (off & 7)) & 1) ? lg : -INFINITY;
-            }
+            if (mask_bits) lg = ((mask_win[kbk] >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1) ? lg : -INFINITY;
             s_acc[kbk][r] = lg;
           }
       }
