@@ -152,3 +152,109 @@ def test_shared_prefix_decode_wrapper_and_sharded_path_world1():
     torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=2e-3, atol=2e-3)
     v_x, s_x = D.exchange_partial_states(o, torch.zeros(batch, hq, device=DEV))
     assert v_x.shape == (batch, 1, hq, d) and torch.equal(v_x[:, 0], o)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_three_level_cascade_random_shapes_match_flat_attention(seed):
+    """MultiLevelCascadeAttentionWrapper with 3 levels (global prefix -> group prefix -> unique suffix with
+    several query rows per request, causal on the last level only; ref: flashinfer/cascade.py:228-555):
+    the merged result must equal flat causal attention over [global | group | unique]."""
+    import random
+
+    import flashinfer
+
+    rng = random.Random(seed)
+    hkv = rng.choice([1, 2, 4])
+    hq = hkv * rng.choice([1, 4, 8])
+    d, ps = rng.choice([64, 128]), rng.choice([4, 16])
+    dtype = rng.choice([torch.float16, torch.bfloat16])
+    n_groups = rng.randint(1, 3)
+    reqs_per_group = [rng.randint(1, 3) for _ in range(n_groups)]
+    batch = sum(reqs_per_group)
+    global_len = ps * rng.randint(1, 20)
+    group_lens = [ps * rng.randint(1, 12) for _ in range(n_groups)]
+    uniq_lens = [rng.randint(1, 90) for _ in range(batch)]
+    qo_lens = [rng.randint(1, min(u, 9)) for u in uniq_lens]
+    g = torch.Generator().manual_seed(seed)
+
+    def pages(n_tokens):
+        return -(-n_tokens // ps)
+
+    total_pages = pages(global_len) + sum(pages(x) for x in group_lens) + sum(pages(x) for x in uniq_lens)
+    cache = torch.randn(total_pages + 2, 2, ps, hkv, d, generator=g).to(dtype)
+    perm = torch.randperm(total_pages + 2, generator=g)[:total_pages].to(torch.int32)
+    pos = 0
+
+    def take(n):
+        nonlocal pos
+        out = perm[pos: pos + n]
+        pos += n
+        return out
+
+    glob_idx = take(pages(global_len))
+    grp_idx = [take(pages(x)) for x in group_lens]
+    unq_idx = [take(pages(x)) for x in uniq_lens]
+    q = torch.randn(sum(qo_lens), hq, d, generator=g).to(dtype)
+    qo_cum = [0]
+    for x in qo_lens:
+        qo_cum.append(qo_cum[-1] + x)
+    # level 0: one "request" = all rows; level 1: one per group; level 2: one per request
+    grp_rows = [0]
+    r = 0
+    for n in reqs_per_group:
+        r += n
+        grp_rows.append(qo_cum[r])
+    qo_indptr = [torch.tensor([0, qo_cum[-1]], dtype=torch.int32), torch.tensor(grp_rows, dtype=torch.int32),
+                 torch.tensor(qo_cum, dtype=torch.int32)]
+    kv_indptr = [torch.tensor([0, len(glob_idx)], dtype=torch.int32),
+                 torch.tensor([0] + list(torch.tensor([len(x) for x in grp_idx]).cumsum(0)), dtype=torch.int32),
+                 torch.tensor([0] + list(torch.tensor([len(x) for x in unq_idx]).cumsum(0)), dtype=torch.int32)]
+    kv_indices = [glob_idx, torch.cat(grp_idx), torch.cat(unq_idx)]
+    last = [torch.tensor([ps], dtype=torch.int32), torch.full((n_groups,), ps, dtype=torch.int32),
+            torch.tensor([(u - 1) % ps + 1 for u in uniq_lens], dtype=torch.int32)]
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.MultiLevelCascadeAttentionWrapper(3, ws, "NHD")
+    w.plan([x.to(DEV) for x in qo_indptr], [x.to(DEV) for x in kv_indptr], [x.to(DEV) for x in kv_indices],
+           [x.to(DEV) for x in last], hq, hkv, d, ps, causal=True, q_data_type=dtype)
+    o = w.run(q.to(DEV), cache.to(DEV))
+
+    def rows(idx, n_tokens):
+        kv = cache[idx.long()].float()
+        return kv[:, 0].reshape(-1, hkv, d)[:n_tokens], kv[:, 1].reshape(-1, hkv, d)[:n_tokens]
+
+    kg, vg = rows(glob_idx, global_len)
+    r = 0
+    for gi, n in enumerate(reqs_per_group):
+        kgr, vgr = rows(grp_idx[gi], group_lens[gi])
+        for _ in range(n):
+            ku, vu = rows(unq_idx[r], uniq_lens[r])
+            k_all, v_all = torch.cat([kg, kgr, ku]), torch.cat([vg, vgr, vu])
+            qr = q[qo_cum[r]: qo_cum[r + 1]].float()
+            o_ref, _ = R.attention_ref(qr, k_all, v_all, causal=True)
+            t = dict(rtol=2.0 ** -6, atol=4e-3) if dtype == torch.bfloat16 else dict(rtol=2e-3, atol=2e-3)
+            torch.testing.assert_close(o[qo_cum[r]: qo_cum[r + 1]].float().cpu(), o_ref.float(), **t)
+            r += 1
+
+
+def test_batch_prefill_shared_prefix_wrapper():
+    # ref: flashinfer/cascade.py:797-1075 (deprecated shared-prefix prefill wrapper)
+    import flashinfer
+
+    batch, prefix_len, hq, hkv, d, ps = 3, 96, 8, 2, 128, 16
+    suffix_lens, qo_lens = [20, 33, 7], [20, 5, 7]
+    cache, sh_idx, un_idx, un_indptr, un_last, _ = _two_level_problem(batch, prefix_len, suffix_lens, hq, hkv, d, ps, 9)
+    torch.manual_seed(10)
+    q = torch.randn(sum(qo_lens), hq, d).half()
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    k_shared = cache[sh_idx.long(), 0].reshape(-1, hkv, d).contiguous()
+    v_shared = cache[sh_idx.long(), 1].reshape(-1, hkv, d).contiguous()
+    w = flashinfer.BatchPrefillWithSharedPrefixPagedKVCacheWrapper(torch.zeros(32 << 20, dtype=torch.uint8, device=DEV), "NHD")
+    w.begin_forward(qo_indptr.to(DEV), un_indptr.to(DEV), un_idx.to(DEV), un_last.to(DEV), hq, hkv, d, ps)
+    o = w.forward(q.to(DEV), k_shared.to(DEV), v_shared.to(DEV), cache.to(DEV), causal=True)
+    for r in range(batch):
+        pages = un_idx[int(un_indptr[r]):int(un_indptr[r + 1])].long()
+        ku = cache[pages, 0].reshape(-1, hkv, d)[: suffix_lens[r]]
+        vu = cache[pages, 1].reshape(-1, hkv, d)[: suffix_lens[r]]
+        qr = q[int(qo_indptr[r]): int(qo_indptr[r + 1])].float()
+        o_ref, _ = R.attention_ref(qr, torch.cat([k_shared, ku]).float(), torch.cat([v_shared, vu]).float(), causal=True)
+        torch.testing.assert_close(o[int(qo_indptr[r]): int(qo_indptr[r + 1])].float().cpu(), o_ref.float(), rtol=2e-3, atol=2e-3)
