@@ -358,3 +358,55 @@ def test_prefill_head_dim_256(dtype, causal):
     os_ref, lses_ref = R.attention_ref(qs.float(), k.float(), v.float(), causal=causal, pos_encoding_mode="ROPE_LLAMA")
     torch.testing.assert_close(os_.float().cpu(), os_ref.float(), **ptol(dtype))
     torch.testing.assert_close(lses.cpu(), lses_ref.float(), rtol=2e-3, atol=2e-3)
+
+
+def test_prefill_run_is_graph_capturable_and_replays_after_replan():
+    """run() only launches kernels on the current stream: capture it once in a HIP graph, then replay after
+    plan() rewrote the work list for other lengths (fixed-shape graph-mode plan; ref: prefill.py:1838-1857)."""
+    import flashinfer
+
+    hq, hkv, d, ps, b = 8, 2, 128, 16, 2
+    rows = 96
+    ws = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(
+        ws, "NHD", use_cuda_graph=True, qo_indptr_buf=torch.zeros(b + 1, dtype=torch.int32, device=DEV),
+        paged_kv_indptr_buf=torch.zeros(b + 1, dtype=torch.int32, device=DEV),
+        paged_kv_indices_buf=torch.zeros(512, dtype=torch.int32, device=DEV),
+        paged_kv_last_page_len_buf=torch.zeros(b, dtype=torch.int32, device=DEV))
+    cases = [([1000, 300], [40, 56]), ([70, 2000], [90, 6])]
+    data = []
+    for seed, (kv_lens, qo_lens) in enumerate(cases):
+        cache, indptr, indices, last = make_paged(b, kv_lens, ps, hkv, d, torch.float16, "NHD", seed=70 + seed,
+                                                  extra_pages=200 - sum(-(-l // ps) for l in kv_lens))
+        data.append((cache, indptr, indices, last, qo_lens))
+    n_pages = data[0][0].shape[0]
+    assert all(x[0].shape[0] == n_pages for x in data)
+    cache_dev = torch.empty_like(data[0][0], device=DEV)
+    q_dev = torch.zeros(rows, hq, d, dtype=torch.float16, device=DEV)
+    out = torch.zeros_like(q_dev)
+
+    def plan(i):
+        cache, indptr, indices, last, qo_lens = data[i]
+        qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+        w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, causal=True, max_token_per_sequence=rows // b)
+        cache_dev.copy_(cache)
+        torch.manual_seed(i)
+        q = torch.randn(rows, hq, d).half()
+        q_dev.copy_(q)
+        return q, qo_indptr
+
+    q, qo_indptr = plan(0)
+    w.run(q_dev, cache_dev, out=out)  # warm-up outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        w.run(q_dev, cache_dev, out=out)
+    for i in (0, 1, 0):
+        q, qo_indptr = plan(i)
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        cache, indptr, indices, last, qo_lens = data[i]
+        n = sum(qo_lens)
+        o_ref, _ = R.batch_prefill_ref(q[:n].float(), qo_indptr, cache.float(), "NHD", indptr, indices, last, causal=True)
+        torch.testing.assert_close(out[:n].float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
