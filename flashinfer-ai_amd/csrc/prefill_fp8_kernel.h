@@ -184,24 +184,23 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   };
 
   // ---- per-lane LDS read offsets ----
-  int k_rd[2][2];  // [kk][half]: K row lq (+32 kb), 16-byte chunks 4 kk + 2 lh (+1)
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) k_rd[kk][e] = k_lds_off(lq, 4 * kk + 2 * lh + e);
+  // K fragment: row lq (+32 kb), 16-byte chunks 4 kk + 2 lh + e.  The three chunk bits are disjoint
+  // (bit 0: e, bit 1: lh, bit 2: kk), so every address is ONE lane-constant base XOR a literal -- one
+  // register instead of four (the kernel sits at the 256-register line; see the spill note below)
+  int k_rd_base = k_lds_off(lq, 2 * lh);
+  auto k_rd = [&](int kk, int e) { return k_rd_base ^ ((4 * kk + e) << 4); };
   // V^T fragment (A operand): lane (d = 32 db + 16 g + j, lh) needs, as byte p = 8 r + b of its 32 bytes,
   // V[kv(p)][d] with kv(p) = 32 (p >> 4) + 8 ((p & 15) >> 2) + 4 lh + (p & 3) -- the order in which the
   // S^T accumulator registers hold P.  Transposed read r covers p = 8 r .. 8 r + 7: rows
   // 32 (r >> 1) + 16 (r & 1) + 4 lh + {0..3, 8..11}; lane i of the 16-lane group addresses row b = i >> 1,
   // bytes 8 (i & 1) .. +8 of chunk 2 db + g.
-  int v_rd[DBLK];
+  int v_rd_base;  // chunk 2 db + g: db occupies chunk bits 1-2, so v_rd(db) = base ^ (db << 5)
   {
     const int i16 = lane & 15, g = (lane >> 4) & 1, b = i16 >> 1;
     const int row = 4 * lh + (b & 3) + 8 * (b >> 2);
-#pragma unroll
-    for (int db = 0; db < DBLK; ++db)
-      v_rd[db] = row * V_ROWB + (((2 * db + g) ^ v_swz(row)) << 4) + 8 * (i16 & 1);
+    v_rd_base = row * V_ROWB + ((g ^ v_swz(row)) << 4) + 8 * (i16 & 1);
   }
+  auto v_rd = [&](int db) { return v_rd_base ^ (db << 5); };
 
   f32x16 o_acc[DBLK];
 #pragma unroll
@@ -225,6 +224,10 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     // is no branch around a load.  The row-offset table of tile t+2 is produced during tile t by wave t % 4.
     auto tile_body = [&](auto buf_c, const int t) {
       constexpr int buf = decltype(buf_c)::value;
+      // keep the derived LDS addresses out of the loop-invariant set: hoisted, they cost four registers
+      // each, get spilled, and every reload (a VMEM op) drags a vmcnt(0) wait -- on the K/V loads just
+      // issued -- into the MFMA section
+      asm volatile("" : "+v"(k_rd_base), "+v"(v_rd_base));
       issue_loads((t + 1) & 3, st);
       const bool tab_wave = wave == (t & 3);
       int tab_pg = 0, tab_en = 0;
@@ -241,8 +244,8 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
         for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-          const u32x4 lo = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd[kk][0]);
-          const u32x4 hi = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd[kk][1]);
+          const u32x4 lo = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd(kk, 0));
+          const u32x4 hi = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd(kk, 1));
           const i32x8 a = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
           s_acc[kbk] = mfma_fp8_k64(a, qf[kk], s_acc[kbk]);
         }
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const i32x2 w = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-              (__attribute__((address_space(3))) i32x2*)(vb + (32 * (r >> 1) + 16 * (r & 1)) * V_ROWB + v_rd[db]));
+              (__attribute__((address_space(3))) i32x2*)(vb + (32 * (r >> 1) + 16 * (r & 1)) * V_ROWB + v_rd(db)));
           a[2 * r] = w[0];
           a[2 * r + 1] = w[1];
         }
