@@ -447,21 +447,24 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
 
   // ---- per-lane LDS read addresses ----
   // K fragment (A operand): row 32 kb + lq, chunk (2 ks + lh) ^ swizzle(row)
-  int k_rd[KSTEPS];
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = k_lds_off(lq, 2 * ks + lh);
+  // chunk 2 ks + lh = (2 ks) ^ lh (disjoint bits), so k_rd(ks) = k_rd_base ^ (ks << 5): ONE lane-constant
+  // register; the tile body re-derives the per-step addresses (an asm barrier keeps them from being
+  // hoisted: as loop invariants they cost KSTEPS + DBLK registers, and in the variants that spill every
+  // in-loop reload -- a VMEM op -- drags a vmcnt(0) wait on the freshly issued K/V loads into the MFMAs)
+  int k_rd_base = k_lds_off(lq, lh);
+  auto k_rd = [&](int ks) { return k_rd_base ^ (ks << 5); };
   // V^T fragment via transposed read: within a 16-lane group, lane 4*q4 + p4 addresses row q4,
   // columns 4 p4 .. 4 p4 + 3 of a 4 x 16 block; the group's block is rows 16 s + 4 lh + (0..3) [+8],
   // columns 32 db + 16 gpar + (0..15)
   const int q4 = (lane & 15) >> 2, p4 = lane & 3, gpar = (lane >> 4) & 1;
-  int v_rd[DBLK];
-#pragma unroll
-  for (int db = 0; db < DBLK; ++db) {
+  int v_rd_base;  // 64-byte group db ^ f: v_rd(db) = v_rd_base ^ (db << 6)
+  {
     const int row = 4 * lh + q4;
-    const int col_byte = (32 * db + 16 * gpar + 4 * p4) * 2;
+    const int col_byte = (16 * gpar + 4 * p4) * 2;
     const int f = (ROWB >= 256) ? (row & 3) : ((row >> 1) & 1);
-    v_rd[db] = row * ROWB + ((((col_byte >> 6) ^ f)) << 6) + (col_byte & 63);
+    v_rd_base = row * ROWB + (f << 6) + col_byte;
   }
+  auto v_rd = [&](int db) { return v_rd_base ^ (db << 6); };
 
   // ---- running state ----
   f32x16 o_acc[DBLK];
@@ -497,6 +500,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     // into the idle buffer): no branch around a load, so the compiler's vmcnt counts stay exact.
     auto tile_body = [&](auto buf_c, const int t) {
       constexpr int buf = decltype(buf_c)::value;
+      asm volatile("" : "+v"(k_rd_base), "+v"(v_rd_base));
       const int t_next = tile_base + min(t + 1, num_tiles - 1);
       write_k(t_next, buf ^ 1, kst);     // K rows of tile t+1 (loaded during tile t-1)
       read_offsets((t + 2) & 3, roff);
@@ -522,7 +526,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
         constexpr int PF = kQkPrefetch;
         u32x4 kf[NK];
         auto rd = [&](int i) {
-          return *(const u32x4*)(kb + (i / KSTEPS) * 32 * ROWB + k_rd[i % KSTEPS]);
+          return *(const u32x4*)(kb + (i / KSTEPS) * 32 * ROWB + k_rd(i % KSTEPS));
         };
 #pragma unroll
         for (int i = 0; i < PF; ++i) kf[i] = rd(i);
@@ -651,7 +655,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
           const frag_t pfrag = __builtin_bit_cast(frag_t, w);
 #pragma unroll
           for (int db = 0; db < DBLK; ++db) {
-            const char* base = vb + (32 * kbk + 16 * s2) * ROWB + v_rd[db];
+            const char* base = vb + (32 * kbk + 16 * s2) * ROWB + v_rd(db);
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                 (__attribute__((address_space(3))) s16x4*)(base));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
