@@ -354,7 +354,6 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
 
 extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a, void* tmp,
                                             size_t tmp_bytes, fi_stream_t stream_) {
-  (void)tmp; (void)tmp_bytes;
   hipStream_t stream = (hipStream_t)stream_;
   FI_REQUIRE(a, "single_prefill_run: null params");
   if (a->qo_len == 0) return 0;
@@ -417,10 +416,46 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
+  // split the kv axis when the q tiles alone cannot fill the chip and the caller lent a scratch buffer
+  // (same search as the batch planner; ref: PrefillBinarySearchKVChunkSize, scheduler.cuh:101-130)
+  if (tmp && tmp_bytes > 0 && a->mask_mode != FI_MASK_CUSTOM) {
+    const int64_t q_tiles = kp.num_work;
+    const int64_t max_items = std::max<int64_t>((int64_t)fi_num_compute_units() * 2 / a->num_kv_heads, 1);
+    int64_t span = std::max<int64_t>(a->kv_len, 1);
+    if (a->window_left >= 0)
+      span = std::min<int64_t>(span, (int64_t)a->window_left + (kp.causal ? kTileQ : a->qo_len) + kTileKV);
+    int64_t low = 128 / kTileKV, high = ceil_div<int64_t>(span, kTileKV);
+    while (low < high) {
+      const int64_t mid = (low + high) / 2;
+      if (q_tiles * ceil_div<int64_t>(span, mid * kTileKV) > max_items) low = mid + 1; else high = mid;
+    }
+    int64_t chunk = std::max<int64_t>(low, 128 / kTileKV) * kTileKV;
+    auto need = [&](int64_t c) {
+      return ((int64_t)a->qo_len * ceil_div<int64_t>(span, c) * a->num_qo_heads * (a->head_dim + 1) + 64) *
+             (int64_t)sizeof(float);
+    };
+    while (chunk < span && need(chunk) > (int64_t)tmp_bytes) chunk *= 2;
+    const int64_t nchunks = ceil_div<int64_t>(span, chunk);
+    if (nchunks > 1 && q_tiles * nchunks < (1ll << 30)) {
+      kp.num_kv_chunks = (int32_t)nchunks;
+      kp.kv_chunk_size = (int32_t)chunk;
+      kp.num_work = (int32_t)(q_tiles * nchunks);
+      kp.tmp_o = (float*)tmp;
+      size_t vbytes = (size_t)a->qo_len * nchunks * a->num_qo_heads * a->head_dim * sizeof(float);
+      vbytes = (vbytes + 15) / 16 * 16;
+      kp.tmp_lse = (float*)((char*)tmp + vbytes);
+    }
+  }
   if (use_fp8_native(kp, a->q_dtype, a->kv_dtype, a->head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA)) {
     FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, stream));
-    return 0;
+  } else {
+    FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
   }
-  FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
+  if (kp.num_kv_chunks > 1) {
+    // partial states are [qo_len, chunks, Hq, D]: the dense n-way merge
+    MergeNParams mp{kp.tmp_o, kp.tmp_lse, nullptr, a->o, a->lse, kp.num_kv_chunks, a->qo_len, a->num_qo_heads,
+                    a->head_dim, FI_DTYPE_F32, a->o_dtype, 0};
+    FI_HIP_CALL(launch_merge_n(mp, stream));
+  }
   return 0;
 }

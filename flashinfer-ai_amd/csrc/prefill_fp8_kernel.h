@@ -70,11 +70,16 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   }
   const int kv_head = logical / p.num_work;
   const int work = logical - kv_head * p.num_work;
-  int req = 0, q_tile = work;
+  int req = 0, q_tile = work, kv_chunk = 0;
+  const bool split = p.kv_tile_indices != nullptr || p.num_kv_chunks > 1;  // see prefill_kernel.h
   if (p.request_indices) {
     req = p.request_indices[work];
     q_tile = p.qo_tile_indices[work];
     if (req < 0) return;
+    if (p.kv_tile_indices) kv_chunk = p.kv_tile_indices[work];
+  } else if (p.num_kv_chunks > 1) {
+    q_tile = work / p.num_kv_chunks;
+    kv_chunk = work - q_tile * p.num_kv_chunks;
   }
   int qo_start = 0, qo_len, kv_len, page_begin = 0;
   if (p.qo_indptr) {
@@ -127,9 +132,8 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
-  int kv_begin = 0, kv_chunk = 0;
-  if (p.kv_tile_indices) {  // split-KV work item (see prefill_kernel.h)
-    kv_chunk = p.kv_tile_indices[work];
+  int kv_begin = 0;
+  if (split) {  // split-KV work item (see prefill_kernel.h)
     kv_begin = kv_chunk * p.kv_chunk_size;
     kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
   }
@@ -334,8 +338,9 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
   if (p.scale_v) inv *= p.scale_v[kv_head];
-  if (row_valid && p.kv_tile_indices) {
-    const int64_t entry = (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk;
+  if (row_valid && split) {
+    const int64_t entry = p.merge_indptr ? (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk
+                                         : (int64_t)(qo_start + qo_idx) * p.num_kv_chunks + kv_chunk;
     const int64_t ob = (entry * p.num_qo_heads + qo_head) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {

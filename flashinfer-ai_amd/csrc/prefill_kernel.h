@@ -52,6 +52,7 @@ struct PrefillKernelParams {
   float* tmp_o;
   float* tmp_lse;
   int32_t kv_chunk_size;           // tokens, a multiple of the 64-row kv tile
+  int32_t num_kv_chunks;           // single-request split (no work list): work = q tile * chunks + chunk
   const float* alibi_slopes;
   const float* scale_q;  // fp8: per qo head / kv head scales (NULL = 1)
   const float* scale_k;
@@ -203,11 +204,16 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   }
   const int kv_head = logical / p.num_work;
   const int work = logical - kv_head * p.num_work;
-  int req = 0, q_tile = work;
+  int req = 0, q_tile = work, kv_chunk = 0;
+  const bool split = p.kv_tile_indices != nullptr || p.num_kv_chunks > 1;
   if (p.request_indices) {
     req = p.request_indices[work];
     q_tile = p.qo_tile_indices[work];
     if (req < 0) return;  // padding item of a fixed-shape (graph) launch; uniform for the workgroup
+    if (p.kv_tile_indices) kv_chunk = p.kv_tile_indices[work];
+  } else if (p.num_kv_chunks > 1) {
+    q_tile = work / p.num_kv_chunks;
+    kv_chunk = work - q_tile * p.num_kv_chunks;
   }
   int qo_start = 0, qo_len, kv_len, page_begin = 0;
   if (p.qo_indptr) {
@@ -307,14 +313,13 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   }
   // sliding window: keys left of the window of the tile's FIRST query row are visible to no row of the
   // tile; start at the kv tile that contains that boundary (ref: kv_start_idx, prefill.cuh:1794-1801)
-  int kv_begin = 0, kv_chunk = 0;
+  int kv_begin = 0;
   if (p.window_left >= 0) {
     const int first_pr = min(q_tile * kTileQ, max(packed_len - 1, 0));
     const int first_qo = (int)fast_div((uint32_t)first_pr, p.group_div);
     kv_begin = max(kv_len - qo_len + first_qo - p.window_left, 0) / kTileKV * kTileKV;
   }
-  if (p.kv_tile_indices) {
-    kv_chunk = p.kv_tile_indices[work];
+  if (split) {
     kv_begin += kv_chunk * p.kv_chunk_size;
     kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
   }
@@ -685,9 +690,10 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   float inv = empty ? 0.f : 1.0f / l_run;
   if constexpr (Q_FP8) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
   else if (p.scale_v) inv *= p.scale_v[kv_head];
-  if (row_valid && p.kv_tile_indices) {
+  if (row_valid && split) {
     // partial state of this kv chunk: normalised f32 o + base-2 lse (ref: prefill.cuh:2378-2403)
-    const int64_t entry = (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk;
+    const int64_t entry = p.merge_indptr ? (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk
+                                         : (int64_t)(qo_start + qo_idx) * p.num_kv_chunks + kv_chunk;
     const int64_t ob = (entry * p.num_qo_heads + qo_head) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {

@@ -187,9 +187,12 @@ def single_prefill_with_kv_cache(
         logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
         rope_rcp_theta=1.0 / rope_theta,
     )
+    # scratch for split-KV partial states (ref: the 32 MB cached buffer of single_prefill, prefill.py:1125)
+    tmp = _get_cache_buf("single_prefill_with_kv_cache_tmp", 32 * 1024 * 1024, q.device)
     with torch.cuda.device(q.device):
         _lib.check(
-            _lib.lib().fi_single_prefill_run(C.byref(params), None, 0, _lib.current_stream(q.device)),
+            _lib.lib().fi_single_prefill_run(C.byref(params), tmp.data_ptr(), tmp.numel() * tmp.element_size(),
+                                             _lib.current_stream(q.device)),
             "single_prefill_with_kv_cache",
         )
     return (out, lse) if return_lse else out

@@ -410,3 +410,28 @@ def test_prefill_run_is_graph_capturable_and_replays_after_replan():
         n = sum(qo_lens)
         o_ref, _ = R.batch_prefill_ref(q[:n].float(), qo_indptr, cache.float(), "NHD", indptr, indices, last, causal=True)
         torch.testing.assert_close(out[:n].float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("qo_len,kv_len", [(1, 20000), (100, 9000), (130, 131)])
+def test_single_prefill_splits_long_kv(causal, qo_len, kv_len):
+    """A few query rows on a long context: the single-request entry point splits the kv axis itself
+    (scratch from the cached buffer) and merges; window and fp8 variants ride the same path."""
+    import flashinfer
+
+    hq, hkv, d = 8, 2, 128
+    torch.manual_seed(qo_len)
+    q = torch.randn(qo_len, hq, d).half()
+    k, v = torch.randn(kv_len, hkv, d).half(), torch.randn(kv_len, hkv, d).half()
+    o, lse = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, return_lse=True)
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), causal=causal)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    o = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, window_left=3000)
+    o_ref, _ = R.attention_ref(q.float(), k.float(), v.float(), causal=causal, window_left=3000)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    mask = torch.rand(qo_len, kv_len) < 0.5
+    mask[:, 0] = True
+    o = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), custom_mask=mask.to(DEV))
+    o_ref, _ = R.attention_ref(q.float(), k.float(), v.float(), custom_mask=mask)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
