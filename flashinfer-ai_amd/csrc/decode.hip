@@ -14,10 +14,10 @@ namespace fi {
 #define FI_DECL(DT, HD)                                                                   \
   hipError_t decode_launch_##DT##_##HD(const DecodeKernelParams& p, int gt, int rope, int grid, \
                                        hipStream_t stream);
-FI_DECL(0, 64) FI_DECL(0, 128) FI_DECL(0, 256)
-FI_DECL(1, 64) FI_DECL(1, 128) FI_DECL(1, 256)
-FI_DECL(2, 64) FI_DECL(2, 128) FI_DECL(2, 256)
-FI_DECL(3, 64) FI_DECL(3, 128) FI_DECL(3, 256)
+FI_DECL(0, 64) FI_DECL(0, 128) FI_DECL(0, 256) FI_DECL(0, 512)
+FI_DECL(1, 64) FI_DECL(1, 128) FI_DECL(1, 256) FI_DECL(1, 512)
+FI_DECL(2, 64) FI_DECL(2, 128) FI_DECL(2, 256) FI_DECL(2, 512)
+FI_DECL(3, 64) FI_DECL(3, 128) FI_DECL(3, 256) FI_DECL(3, 512)
 #undef FI_DECL
 
 typedef hipError_t (*decode_launch_fn)(const DecodeKernelParams&, int, int, int, hipStream_t);
@@ -32,6 +32,8 @@ static decode_launch_fn find_launcher(int kv_dt, int head_dim) {
         return decode_launch_##DT##_128;    \
       case 256:                             \
         return decode_launch_##DT##_256;    \
+      case 512:                             \
+        return decode_launch_##DT##_512;    \
       default:                              \
         return nullptr;                     \
     }

@@ -112,7 +112,7 @@ def test_batch_decode_wide_group_no_split_and_graph_padding():
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("d", [64, 128, 256, 512])
 @pytest.mark.parametrize("kv_dtype", [torch.float16, torch.float8_e4m3fn, torch.float8_e5m2])
 def test_batch_decode_head_dims_and_fp8_kv(d, kv_dtype):
     hq, hkv, page_size = 8, 2, 16
@@ -350,3 +350,15 @@ def test_fast_decode_plan_matches_plan():
     assert torch.equal(o, o_ref) or torch.allclose(o.float(), o_ref.float(), rtol=1e-3, atol=1e-3)
     o_ora, _ = R.batch_decode_ref(q.float().cpu(), cache.float(), "NHD", indptr, indices, last)
     torch.testing.assert_close(o.float().cpu(), o_ora.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_single_decode_head_dim_512():
+    import flashinfer
+
+    torch.manual_seed(2)
+    q = torch.randn(8, 512).half()
+    k, v = torch.randn(700, 2, 512).half(), torch.randn(700, 2, 512).half()
+    o, lse = flashinfer.single_decode_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), return_lse=True)
+    o_ref, lse_ref = R.single_decode_ref(q.float(), k.float(), v.float())
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
