@@ -67,7 +67,9 @@ static int pick_head_tile(int group_size, int kv_dt = FI_DTYPE_BF16) {
 // dtype.  FI_DECODE_MFMA_MIN_GROUP moves the crossover (0 disables the path).
 hipError_t decode_mfma_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int grid,
                               hipStream_t stream);
-static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim) {
+static int tokens_per_load(int kv_dt, int head_dim);
+static int ilog2_exact(int x);
+static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim, int page_size) {
   static const int min_group = [] {
     const char* e = getenv("FI_DECODE_MFMA_MIN_GROUP");
     return e ? atoi(e) : 5;
@@ -79,7 +81,11 @@ static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim)
     return e ? atoi(e) : 3;
   }();
   const bool fp8 = kv_dt == FI_DTYPE_FP8_E4M3 || kv_dt == FI_DTYPE_FP8_E5M2;
-  const int mg = fp8 ? min_group_fp8 : min_group;
+  int mg = fp8 ? min_group_fp8 : min_group;
+  // pages too small (or not a power of two) for the VALU kernel's scalar-page fast path: its per-lane
+  // page-lookup fallback runs at 4.5 TB/s (page_size 1), the matrix-core kernel -- which always gathers per
+  // lane -- at 6.3; token-granular page tables (page_size 1) are common
+  if (mg > 0 && (ilog2_exact(page_size) < 0 || page_size < tokens_per_load(kv_dt, head_dim))) mg = 1;
   return mg > 0 && group_size >= mg && group_size <= 32 && (q_dt == kv_dt || fp8) &&
          (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) && (head_dim == 64 || head_dim == 128);
 }
@@ -153,7 +159,7 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
   const int gt = pick_head_tile(group, kv_dtype);
   // the matrix-core kernel covers the whole group with one wave; a run() that cannot use it (rope, alibi,
   // soft cap, window) still works on this plan, with head_tiles x the work items
-  const int head_tiles = mfma_decode_shape(group, q_dtype, kv_dtype, head_dim) ? 1 : ceil_div(group, gt);
+  const int head_tiles = mfma_decode_shape(group, q_dtype, kv_dtype, head_dim, page_size) ? 1 : ceil_div(group, gt);
   const uint32_t gdy = (uint32_t)(num_kv_heads * head_tiles);
   // head tiles of one kv head stream the same rows (the partner wave's loads hit in L2), so a multi-tile
   // launch is sized for twice the waves: measured 4.42 vs 3.73 TB/s at Hq/Hkv = 64/8 (r1)
@@ -343,7 +349,7 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   kp.kv_stride_page = kv.stride_page;
   kp.kv_stride_n = kv.stride_n;
   kp.kv_stride_h = kv.stride_h;
-  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim) &&
+  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim, kv.page_size) &&
                         a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
                         kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
   if (use_mfma) kp.head_tiles = 1;
@@ -435,7 +441,7 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
 
-  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim) &&
+  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim, vpage) &&
                         a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
                         kp.kv_stride_page < (1ll << 31);
   if (use_mfma) kp.head_tiles = 1;

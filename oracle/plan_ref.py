@@ -26,11 +26,16 @@ def pick_head_tile(group_size: int, kv_bytes: int = 2) -> int:
     return 4
 
 
-def head_tiles(group_size: int, kv_bytes: int = 2, head_dim: int = 128) -> int:
+def head_tiles(group_size: int, kv_bytes: int = 2, head_dim: int = 128, page_size: int = 16) -> int:
     """Work items per (request chunk, kv head).  Groups of 5..32 heads (3..32 with an fp8 cache) at
     head_dim 64/128 run on the matrix-core decode kernel, where one wave covers the whole group; smaller
     groups use the VALU kernel's q-head tiles of <= 4 heads (flashinfer-ai_amd/csrc/decode.hip)."""
     min_group = 3 if kv_bytes == 1 else 5
+    # pages too small / not a power of two for the VALU kernel's scalar-page path: matrix-core kernel for
+    # every group size
+    tokens_per_load = 64 // (head_dim // (16 // kv_bytes))
+    if page_size & (page_size - 1) or page_size < tokens_per_load:
+        min_group = 1
     if min_group <= group_size <= 32 and head_dim in (64, 128):
         return 1
     return ceil_div(group_size, pick_head_tile(group_size, kv_bytes))
@@ -53,7 +58,7 @@ def decode_plan_ref(indptr: List[int], num_qo_heads: int, num_kv_heads: int, pag
                     window_left: int = -1):
     batch = len(indptr) - 1
     group = num_qo_heads // num_kv_heads
-    gdy = num_kv_heads * head_tiles(group, kv_bytes, head_dim)
+    gdy = num_kv_heads * head_tiles(group, kv_bytes, head_dim, page_size)
     num_pages = [indptr[i + 1] - indptr[i] for i in range(batch)]
     if window_left >= 0:
         # only the pages from the one holding the earliest key the last token can see are partitioned
