@@ -86,7 +86,7 @@ static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim,
   // page-lookup fallback runs at 4.5 TB/s (page_size 1), the matrix-core kernel -- which always gathers per
   // lane -- at 6.3; token-granular page tables (page_size 1) are common
   if (mg > 0 && (ilog2_exact(page_size) < 0 || page_size < tokens_per_load(kv_dt, head_dim))) mg = 1;
-  return mg > 0 && group_size >= mg && group_size <= 32 && (q_dt == kv_dt || fp8) &&
+  return mg > 0 && group_size >= mg && (q_dt == kv_dt || fp8) &&
          (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) && (head_dim == 64 || head_dim == 128);
 }
 
@@ -159,7 +159,7 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
   const int gt = pick_head_tile(group, kv_dtype);
   // the matrix-core kernel covers the whole group with one wave; a run() that cannot use it (rope, alibi,
   // soft cap, window) still works on this plan, with head_tiles x the work items
-  const int head_tiles = mfma_decode_shape(group, q_dtype, kv_dtype, head_dim, page_size) ? 1 : ceil_div(group, gt);
+  const int head_tiles = mfma_decode_shape(group, q_dtype, kv_dtype, head_dim, page_size) ? ceil_div(group, 32) : ceil_div(group, gt);
   const uint32_t gdy = (uint32_t)(num_kv_heads * head_tiles);
   // head tiles of one kv head stream the same rows (the partner wave's loads hit in L2), so a multi-tile
   // launch is sized for twice the waves: measured 4.42 vs 3.73 TB/s at Hq/Hkv = 64/8 (r1)
@@ -352,7 +352,7 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim, kv.page_size) &&
                         a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
                         kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
-  if (use_mfma) kp.head_tiles = 1;
+  if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   kp.num_items = (int32_t)(padded * kv.num_kv_heads * kp.head_tiles);
   kp.kv_chunk_size = (int32_t)plan_info[FI_DP_KV_CHUNK_SIZE];
   kp.split_kv = split;
@@ -444,7 +444,7 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim, vpage) &&
                         a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
                         kp.kv_stride_page < (1ll << 31);
-  if (use_mfma) kp.head_tiles = 1;
+  if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   // split-KV so that the chip is filled (ref: decode.cuh:689-733, kv_len > 256 -> chunks >= 256)
   const int gdy = a->num_kv_heads * kp.head_tiles;
   const int max_grid = fi_num_compute_units() * decode_waves_per_cu();

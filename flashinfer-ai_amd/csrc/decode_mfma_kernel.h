@@ -52,9 +52,11 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
   char* const vb = kb + TILE_BYTES;
   const int lq = lane & 31, lh = lane >> 5;
 
-  // ---- item -> (work, kv head); same work list as the VALU kernel with one head tile ----
-  const int kv_head = item % p.num_kv_heads;
-  const int work = item / p.num_kv_heads;
+  // ---- item -> (work, kv head, 32-head column block); the work list is the VALU kernel's, with one
+  // head tile per 32 query heads of the group (one tile for every group up to 32) ----
+  const int col_blk = item % p.head_tiles;
+  const int kv_head = (item / p.head_tiles) % p.num_kv_heads;
+  const int work = item / (p.head_tiles * p.num_kv_heads);
   int req = 0, kv_tile = work;
   if (p.request_indices) {
     if (p.block_valid_mask && !p.block_valid_mask[work]) return;
@@ -81,8 +83,9 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
   int chunk_start = chunk_base + (p.split_kv ? kv_tile * p.kv_chunk_size : 0);
   const int chunk_end = p.split_kv ? min(chunk_start + p.kv_chunk_size, kv_len) : kv_len;
   if (win_start > chunk_start) chunk_start += (win_start - chunk_start) / kDmTileKV * kDmTileKV;
-  const int G = p.group_size;
-  const int head = kv_head * G + min(lq, G - 1);
+  const int G = min(p.group_size - 32 * col_blk, 32);  // heads of this column block
+  const int head0 = kv_head * p.group_size + 32 * col_blk;
+  const int head = head0 + min(lq, G - 1);
 
   // ---- Q fragments: lane (q = head column, h) holds Q[head][16 ks + 8 h + 0..7] ----
   frag_t qf[KSTEPS];
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
   const float inv = empty ? 0.f : 1.0f / l_run;
   const float lse_v = empty ? FI_NEG_INF : m_run + fast_log2(l_run);
   if (lq < G) {
-    const int qo_head = kv_head * G + lq;
+    const int qo_head = head0 + lq;
     const int64_t out_row = p.split_kv ? (int64_t)(p.o_indptr ? p.o_indptr[req] : 0) + kv_tile : req;
     const int64_t ob = (out_row * p.num_qo_heads + qo_head) * D;
 #pragma unroll

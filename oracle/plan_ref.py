@@ -27,7 +27,7 @@ def pick_head_tile(group_size: int, kv_bytes: int = 2) -> int:
 
 
 def head_tiles(group_size: int, kv_bytes: int = 2, head_dim: int = 128, page_size: int = 16) -> int:
-    """Work items per (request chunk, kv head).  Groups of 5..32 heads (3..32 with an fp8 cache) at
+    """Work items per (request chunk, kv head).  Groups of >= 5 heads (>= 3 with an fp8 cache; one work item per 32 heads) at
     head_dim 64/128 run on the matrix-core decode kernel, where one wave covers the whole group; smaller
     groups use the VALU kernel's q-head tiles of <= 4 heads (flashinfer-ai_amd/csrc/decode.hip)."""
     min_group = 3 if kv_bytes == 1 else 5
@@ -36,8 +36,8 @@ def head_tiles(group_size: int, kv_bytes: int = 2, head_dim: int = 128, page_siz
     tokens_per_load = 64 // (head_dim // (16 // kv_bytes))
     if page_size & (page_size - 1) or page_size < tokens_per_load:
         min_group = 1
-    if min_group <= group_size <= 32 and head_dim in (64, 128):
-        return 1
+    if min_group <= group_size and head_dim in (64, 128):
+        return ceil_div(group_size, 32)  # one wave covers 32 heads of the group
     return ceil_div(group_size, pick_head_tile(group_size, kv_bytes))
 
 

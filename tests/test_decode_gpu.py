@@ -67,9 +67,9 @@ def test_batch_decode_matches_oracle(dtype, layout, page_size, hq, hkv):
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("d", [64, 128])
 @pytest.mark.parametrize("page_size", [5, 16])
-@pytest.mark.parametrize("hq,hkv", [(64, 8), (32, 2), (64, 2), (40, 8), (26, 2)])
+@pytest.mark.parametrize("hq,hkv", [(64, 8), (32, 2), (64, 2), (40, 8), (26, 2), (64, 1), (71, 1)])
 def test_batch_decode_wide_groups_matrix_core_path(dtype, d, page_size, hq, hkv):
-    """Groups of 5..32 query heads per kv head run on the MFMA decode kernel (decode_mfma_kernel.h); the
+    """Groups of >= 5 query heads per kv head (32 per wave) run on the MFMA decode kernel (decode_mfma_kernel.h); the
     reference's counterpart is use_tensor_cores=True (tests/attention/test_tensor_cores_decode.py)."""
     kv_lens = [1, 31, 32, 33, 777, 4096, 64, 2500, 95]
     torch.manual_seed(17)

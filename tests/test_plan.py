@@ -44,7 +44,7 @@ CASES = [
     ([0, 0, 9], 4, 4, 16, 64),                              # empty request (test_decode_prefill_lse.py)
     ([0, 3, 3, 1000], 8, 1, 1, 512),
     ([0, 5], 28, 4, 8, 4096),                               # group 7 -> matrix-core kernel, one item per kv head
-    ([0, 40, 90], 64, 1, 16, 512),                          # group 64 -> 16 VALU head tiles
+    ([0, 40, 90], 64, 1, 16, 512),                          # group 64 -> two 32-head column blocks
 ]
 
 
