@@ -258,3 +258,17 @@ def test_batch_prefill_shared_prefix_wrapper():
         qr = q[int(qo_indptr[r]): int(qo_indptr[r + 1])].float()
         o_ref, _ = R.attention_ref(qr, torch.cat([k_shared, ku]).float(), torch.cat([v_shared, vu]).float(), causal=True)
         torch.testing.assert_close(o[int(qo_indptr[r]): int(qo_indptr[r + 1])].float().cpu(), o_ref.float(), rtol=2e-3, atol=2e-3)
+
+
+def test_serving_loop_example_runs_and_matches_flat_attention():
+    """examples/serving_loop.py: chunked prefill + graph-replayed decode over an appended paged cache."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "serving_loop.py")
+    spec = importlib.util.spec_from_file_location("serving_loop", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out, o1 = mod.main(batch=3, prompt_len=70, new_tokens=5, hq=8, hkv=2, d=128, page_size=16, dtype=torch.float16)
+    assert out.shape == (3 * 70, 8, 128) and o1.shape == (3, 8, 128)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(o1.float()).all()
