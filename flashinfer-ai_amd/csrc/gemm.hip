@@ -282,30 +282,43 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
     if (kb < kblocks) k_step(std::integral_constant<int, 0>{}, kb);
   }
 
-  // ---- epilogue: D[m][n], 4 consecutive n per lane and register quad ----
+  // ---- epilogue ----
+  // The accumulators are transposed (m on the lane): a direct store writes 8-byte pieces.  Each wave turns
+  // its 64 x 64 block through its own 9 KB of LDS ([m][64 n] 16-bit rows, 144-byte stride; every LDS stage
+  // read finished at the loop's last barrier) and stores whole 128-byte rows, 16 bytes per lane.
+  {
+    constexpr int kOutStride = 144;
+    uint8_t* const scratch = &smem[0][0][0] + wave * (64 * kOutStride);
 #pragma unroll
-  for (int mb = 0; mb < 2; ++mb) {
-    const int m = m0 + 64 * wm + 32 * mb + lq;
-    if (m >= m_end) continue;
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int n = n0 + 64 * wn + 32 * nb + 8 * r4 + 4 * lh;
-        if (n >= N) continue;
-        uint32_t w[2];
+        for (int r4 = 0; r4 < 4; ++r4) {
+          uint32_t w[2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const uint32_t lo = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e], p.out_dtype);
-          const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
-          w[e] = lo | (hi << 16);
+          for (int e = 0; e < 2; ++e) {
+            const uint32_t lo = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e], p.out_dtype);
+            const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
+            w[e] = lo | (hi << 16);
+          }
+          *(u32x2*)(scratch + (32 * mb + lq) * kOutStride + (32 * nb + 8 * r4 + 4 * lh) * 2) = u32x2{w[0], w[1]};
         }
-        uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
-        if (n + 4 <= N) {
-          *(u32x2*)dst = u32x2{w[0], w[1]};
-        } else {
-          for (int e = 0; e < N - n; ++e) dst[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
-        }
+    const bool d_aligned16 = (((uintptr_t)p.d) & 15) == 0;
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      const int idx = lane + 64 * i2;
+      const int r = idx >> 3, c = idx & 7;
+      const u32x4 v = *(const u32x4*)(scratch + r * kOutStride + c * 16);
+      const int m = m0 + 64 * wm + r;
+      const int n = n0 + 64 * wn + 8 * c;
+      if (m >= m_end || n >= N) continue;  // n is a multiple of 8 and so is N
+      uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
+      if (d_aligned16) {
+        *(u32x4*)dst = v;
+      } else {
+        *(u32x2*)dst = u32x2{v[0], v[1]};
+        *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};
       }
     }
   }
@@ -366,18 +379,20 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(cons
   f32x16g acc[2][2];  // [n block][m block]
   int out_m0 = 0, out_n0 = 0, out_m_end = 0;  // tile whose accumulators are waiting to be stored
   bool have_out = false;
-  // D[m][n], 4 consecutive n per lane and register quad
+  // Output: the accumulators are transposed (m on the lane), so a direct store writes 8-byte pieces.  Each
+  // wave instead turns its 64 x 64 block through its own 9 KB of LDS ([m][64 n] bf16/f16 rows, 144-byte row
+  // stride) and stores whole 128-byte rows, 16 bytes per lane.  Callers put a workgroup barrier between this
+  // and the next LDS stage store.
+  constexpr int kOutStride = 144;
+  const bool d_aligned16 = (((uintptr_t)p.d) & 15) == 0;
   auto store_tile = [&]() {
+    uint8_t* const scratch = &smem[0][0] + wave * (64 * kOutStride);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const int m = out_m0 + 64 * wm + 32 * mb + lq;
-      if (m >= out_m_end) continue;
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) {
+      for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const int n = out_n0 + 64 * wn + 32 * nb + 8 * r4 + 4 * lh;
-          if (n >= N) continue;
           uint32_t w[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
@@ -385,13 +400,22 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(cons
             const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
             w[e] = lo | (hi << 16);
           }
-          uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
-          if (n + 4 <= N) {
-            *(u32x2*)dst = u32x2{w[0], w[1]};
-          } else {
-            for (int e = 0; e < N - n; ++e) dst[e] = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
-          }
+          *(u32x2*)(scratch + (32 * mb + lq) * kOutStride + (32 * nb + 8 * r4 + 4 * lh) * 2) = u32x2{w[0], w[1]};
         }
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      const int idx = lane + 64 * i2;
+      const int r = idx >> 3, c = idx & 7;
+      const u32x4 v = *(const u32x4*)(scratch + r * kOutStride + c * 16);
+      const int m = out_m0 + 64 * wm + r;
+      const int n = out_n0 + 64 * wn + 8 * c;
+      if (m >= out_m_end || n >= N) continue;  // n is a multiple of 8 and so is N
+      uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
+      if (d_aligned16) {
+        *(u32x4*)dst = v;
+      } else {
+        *(u32x2*)dst = u32x2{v[0], v[1]};
+        *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};
       }
     }
   };
@@ -478,7 +502,10 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(cons
     load_scales(0);
     issue(0, rs0);
     if constexpr (kAhead == 2) issue(1, rs1);
-    if (have_out && !(FI_GEMM_KO & 1)) store_tile();
+    if (have_out && !(FI_GEMM_KO & 1)) {
+      store_tile();
+      __syncthreads();  // the transposition scratch overlaps LDS stage 0
+    }
     out_m0 = m0;
     out_n0 = n0;
     out_m_end = m_end;
