@@ -33,6 +33,24 @@ def test_gemm_fp8_nt_groupwise(m, n, k, mode, out_dtype):
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=1e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("mode", ["MN", "K"])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float16])
+def test_gemm_fp8_nt_groupwise_large(mode, out_dtype):
+    """Enough 256 x 128 tiles (33 x 16 >= 2 x CUs) for the persistent large-problem kernel; random data."""
+    import flashinfer
+
+    torch.manual_seed(5)
+    m, n, k = 8195, 2048, 640
+    a = torch.randn(m, k)
+    b = torch.randn(n, k) / math.sqrt(k)
+    a8, sa = G.quantize_fp8(a, (1, 128), mode)
+    b8, sb = G.quantize_fp8(b, (128, 128), mode)
+    out = flashinfer.gemm_fp8_nt_groupwise(a8.to(DEV), b8.to(DEV), sa.to(DEV), sb.to(DEV), scale_major_mode=mode,
+                                           out_dtype=out_dtype)
+    ref = G.gemm_fp8_nt_groupwise_ref(a8, b8, sa, sb, mode)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
 @pytest.mark.parametrize("ms", [[4, 128, 0, 260], [512, 512], [128] * 8, [4]])
 @pytest.mark.parametrize("n,k", [(256, 256), (512, 1024)])
 @pytest.mark.parametrize("mode", ["MN", "K"])
@@ -92,14 +110,18 @@ def test_gemm_errors():
         flashinfer.gemm_fp8_nt_groupwise(a, a, s, s, scale_major_mode="MN", out_dtype=torch.float32)
 
 
-@pytest.mark.parametrize("ms,n", [([1300, 4, 0, 2300, 520], 400), ([2500], 136), ([128] * 37, 264)])
-def test_group_gemm_exact_many_tiles_banded_order(ms, n):
-    """More m tiles than one band (8) and a ragged last band / last n tile: every (group, m tile, n tile) must
-    be visited exactly once by the banded tile order.  Small integers -> the result is exact."""
+@pytest.mark.parametrize("ms,n,k", [([1300, 4, 0, 2300, 520], 400, 256), ([2500], 136, 256), ([128] * 37, 264, 256),
+                                    # >= 2 x CUs tiles of 256 x 128: the persistent 256 x 128 kernel (ragged groups,
+                                    # an empty group, a partial n tile; odd / even k block counts, one k block)
+                                    ([2300, 4, 0, 3100, 1000, 777], 2696, 256), ([8000], 2056, 384),
+                                    ([255, 257, 6000, 1], 3584, 128)])
+def test_group_gemm_exact_many_tiles_banded_order(ms, n, k):
+    """More m tiles than one band and a ragged last band / last n tile: every (group, m tile, n tile) must
+    be visited exactly once by the banded tile order of either kernel.  Small integers -> the result is exact."""
     import flashinfer
 
     torch.manual_seed(3)
-    g, k = len(ms), 256
+    g = len(ms)
     cum = sum(ms)
     a = torch.randint(-3, 4, (cum, k)).float()
     b = torch.randint(-3, 4, (g, n, k)).float()
