@@ -627,6 +627,284 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(cons
   if (have_out && (!(FI_GEMM_KO & 1) || p.k == 12345)) store_tile();
 }
 
+// ---- the same 256 x 128 persistent kernel with LDS-DMA staging (default for large problems) --------------
+// Operands go global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB per wave instruction), two k blocks
+// ahead through a ring of three 52 KB LDS stages (156 of the 160 KB): no staging registers, no
+// VGPR -> LDS store transfer.  Synchronisation is by hand: every wave waits `vmcnt(8)` (its own pieces of the
+// NEXT block landed, the 8 DMA instructions of the block after it still in flight) and then a raw `s_barrier`
+// -- `__syncthreads()` would drain vmcnt.  FI_GEMM_DMA=0 selects the register-staged kernel above.
+template <bool MA_E5M2, bool MB_E5M2>
+__global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const GemmParams p) {
+  // [stage][A 32 KB | B 16 KB | per wave: 64 A scales, 64 x the B scale]  (one array: the compiler tells a DMA
+  // target from an LDS read by constant offsets inside ONE object; a second array made it wait vmcnt(0))
+  constexpr int kScOff = (kWsBM + kBN) * kBK;
+  __shared__ __attribute__((aligned(1024))) uint8_t smem[3][kScOff + (kWsThreads / 64) * 512];
+  constexpr int kBOff = kWsBM * kBK;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave & 3, wn = wave >> 2;
+  const int lq = lane & 31, lh = lane >> 5;
+  const int K = p.k, N = p.n;
+  const int kblocks = K / kBK;
+  auto lds_off = [](int row, int ch) { return row * kBK + ((ch ^ ((row >> 1) & 7)) << 4); };
+  const int m_cnt = p.a_gran_m == 1 ? p.m_total : (p.m_total + p.a_gran_m - 1) / p.a_gran_m;
+  const int a_sc_stride = p.scale_k_major ? 1 : m_cnt;
+  const int n_sblocks = (N + 127) / 128;
+  const int b_sc_stride = p.scale_k_major ? 1 : n_sblocks;
+  // LDS read addresses: every fragment address is one per-lane base XOR a literal (the k half flips chunk
+  // bit 2, the second 16 bytes chunk bit 0) plus a literal; the bases pass through an empty asm in the loop
+  // so that the derived addresses are recomputed there instead of living in 16 registers
+  uint32_t a_rd_base = (uint32_t)lds_off(64 * wm + lq, 2 * lh);
+  uint32_t b_rd_base = (uint32_t)(kBOff + lds_off(64 * wn + lq, 2 * lh));
+
+  // ---- persistent workgroup: the XCD-contiguous tile range of this XCD, strided by its workgroups ----
+  const int total = p.num_m_tiles_bound * p.n_tiles;
+  int logical, logical_end;
+  const int logical_step = gridDim.x >> 3;
+  {
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int qn = total >> 3, rn = total & 7;
+    const int start = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
+    logical = start + slot;
+    logical_end = start + qn + (xcd < rn ? 1 : 0);
+  }
+
+  f32x16g acc[2][2];  // [n block][m block]
+  int out_m0 = 0, out_n0 = 0, out_m_end = 0;  // tile whose accumulators are waiting to be stored
+  bool have_out = false;
+  // Output: the accumulators are transposed (m on the lane), so a direct store writes 8-byte pieces.  Each
+  // wave instead turns its 64 x 64 block through its own 9 KB of LDS ([m][64 n] bf16/f16 rows, 144-byte row
+  // stride) and stores whole 128-byte rows, 16 bytes per lane.  Callers put a workgroup barrier between this
+  // and the next LDS stage store.
+  constexpr int kOutStride = 144;
+  const bool d_aligned16 = (((uintptr_t)p.d) & 15) == 0;
+  auto store_tile = [&]() {
+    uint8_t* const scratch = &smem[0][0] + wave * (64 * kOutStride);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          uint32_t w[2];
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const uint32_t lo = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e], p.out_dtype);
+            const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
+            w[e] = lo | (hi << 16);
+          }
+          *(u32x2*)(scratch + (32 * mb + lq) * kOutStride + (32 * nb + 8 * r4 + 4 * lh) * 2) = u32x2{w[0], w[1]};
+        }
+#pragma unroll
+    for (int i2 = 0; i2 < 8; ++i2) {
+      const int idx = lane + 64 * i2;
+      const int r = idx >> 3, c = idx & 7;
+      const u32x4 v = *(const u32x4*)(scratch + r * kOutStride + c * 16);
+      const int m = out_m0 + 64 * wm + r;
+      const int n = out_n0 + 64 * wn + 8 * c;
+      if (m >= out_m_end || n >= N) continue;  // n is a multiple of 8 and so is N
+      uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
+      if (d_aligned16) {
+        *(u32x4*)dst = v;
+      } else {
+        *(u32x2*)dst = u32x2{v[0], v[1]};
+        *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};
+      }
+    }
+  };
+
+  for (; logical < logical_end; logical += logical_step) {
+    constexpr int kBandM = 4;  // 1024 rows x all n per band, as in the 128 x 128 kernel
+    const int band_tiles = kBandM * p.n_tiles;
+    const int band = logical / band_tiles;
+    const int in_band = logical - band * band_tiles;
+    const int band_m = min(kBandM, p.num_m_tiles_bound - band * kBandM);
+    const int nt = in_band / band_m;
+    const int mt_global = band * kBandM + (in_band - nt * band_m);
+    int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
+    bool found = true;
+    if (p.m_indptr) {
+      int cnt = 0;
+      found = false;
+      for (int gi = 0; gi < p.num_groups; ++gi) {
+        const int lo = p.m_indptr[gi], hi = p.m_indptr[gi + 1];
+        const int tiles = (hi - lo + kWsBM - 1) / kWsBM;
+        if (!found && mt_global < cnt + tiles) {
+          g = gi;
+          m_begin = lo;
+          m_end = hi;
+          mt = mt_global - cnt;
+          found = true;
+        }
+        cnt += tiles;
+      }
+    } else if (mt_global * kWsBM >= p.m_total) {
+      found = false;
+    }
+    if (!found) continue;  // the grid bound counts one partial tile per group; uniform per workgroup
+    const int m0 = m_begin + mt * kWsBM;
+    const int n0 = nt * kBN;
+    const uint8_t* Bg = p.b + (int64_t)g * N * K;
+
+    // LDS-DMA geometry: the stage image is [384 rows][128 B] (A rows 0-255, B rows 256-383) and a piece =
+    // one wave instruction = 8 rows = 1 KiB of it, written linearly (lane i -> byte 16 i of the piece).  The
+    // XOR swizzle is applied on the GLOBAL side: lane i fetches chunk (i & 7) ^ key(row) of row (i >> 3).
+    // Wave w owns pieces 6 w .. 6 w + 5 of the 48.
+    const uint8_t* const a_tile = p.a + (int64_t)m0 * K;
+    const uint8_t* const b_tile = Bg + (int64_t)n0 * K;
+    uint32_t d_off[6];
+#pragma unroll
+    for (int j2 = 0; j2 < 6; ++j2) {
+      const int row = 8 * (6 * wave + j2) + (lane >> 3);
+      const int ch = (lane & 7) ^ ((row >> 1) & 7);
+      const int r = row < kWsBM ? min(m0 + row, m_end - 1) - m0 : min(n0 + row - kWsBM, N - 1) - n0;
+      d_off[j2] = (uint32_t)r * (uint32_t)K + ch * 16;
+    }
+    // scale sources for the DMA: one A-scale pointer per lane (row 64 wm + lane of the tile), B scale uniform
+    const float* const b_sc = p.scale_k_major ? p.b_scale + ((int64_t)g * n_sblocks + n0 / 128) * kblocks
+                                              : p.b_scale + (int64_t)g * kblocks * n_sblocks + n0 / 128;
+    const float* a_sc_dma;
+    {
+      const int m = min(m0 + 64 * wm + lane, m_end - 1);
+      const int mi = p.a_gran_m == 1 ? m : m / p.a_gran_m;
+      a_sc_dma = p.scale_k_major ? p.a_scale + (int64_t)mi * kblocks : p.a_scale + mi;
+    }
+    auto dma = [&](int kb, int stage) {
+      const uint32_t koff = (uint32_t)(kb * kBK);
+#pragma unroll
+      for (int j2 = 0; j2 < 6; ++j2) {
+        const int q = 6 * wave + j2;
+        const uint8_t* src_p = (q < kWsBM / 8 ? a_tile : b_tile) + (d_off[j2] + koff);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_p,
+                                         (__attribute__((address_space(3))) void*)(&smem[stage][q * 1024]), 16, 0, 0);
+      }
+      // the block's scales travel the same way (4 bytes per lane): lane L's A scale is the one of row
+      // 64 wm + L of the tile, the B scale is fetched by every lane.  They are then ordinary LDS reads; an
+      // ordinary global load in flight beside the DMA would cost a vmcnt(0) at its first use.
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_sc_dma + (int64_t)kb * a_sc_stride),
+                                       (__attribute__((address_space(3))) void*)(&smem[stage][kScOff + wave * 512]), 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_sc + (int64_t)kb * b_sc_stride),
+                                       (__attribute__((address_space(3))) void*)(&smem[stage][kScOff + wave * 512 + 256]), 4, 0, 0);
+    };
+    if (have_out) {
+      store_tile();
+      __syncthreads();  // the transposition scratch overlaps the LDS stages
+    }
+    out_m0 = m0;
+    out_n0 = n0;
+    out_m_end = m_end;
+    have_out = true;
+    dma(0, 0);
+    if (kblocks > 1) dma(1, 1);
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+      for (int j2 = 0; j2 < 2; ++j2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i2][j2][r] = 0.f;
+    if (kblocks > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // D(0) landed, D(1) (8 pieces) in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    f32x16g p_carry;  // block (1, 1) of the previous k step, folded at the start of the next one
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p_carry[r] = 0.f;
+    float s_carry = 0.f;
+
+    auto k_step = [&](auto par_c, const int kb) {
+      constexpr int buf = decltype(par_c)::value;  // == kb % 3
+      if (kb + 2 < kblocks) dma(kb + 2, (buf + 2) % 3);  // D(kb + 2) into the stage read in step kb - 1
+      const float* const sc = (const float*)(&smem[buf][kScOff + wave * 512]);
+      const float sa[2] = {sc[lq], sc[32 + lq]};
+      const float sb = sc[64 + lane];
+      asm volatile("" : "+v"(a_rd_base), "+v"(b_rd_base));
+      const uint8_t* const stage = &smem[buf][0];
+      // One 32 x 32 block at a time, cut into sched_barrier regions: left alone the scheduler hoists every
+      // LDS read and all four partial products to the top and spills ~30 registers.
+      auto frag = [&](uint32_t base, int kk, int blk) {
+        const u32x4 lo = *(const u32x4*)(stage + ((base ^ (kk << 6)) + blk * 32 * kBK));
+        const u32x4 hi = *(const u32x4*)(stage + ((base ^ (kk << 6) ^ 16) + blk * 32 * kBK));
+        return i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      };
+      auto mfma0 = [&](const i32x8g& b, const i32x8g& a) {
+        f32x16g z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, z, MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0,
+                                                               0x7F7F7F7F, 0, 0x7F7F7F7F);
+      };
+      auto mfma1 = [&](const i32x8g& b, const i32x8g& a, const f32x16g& c) {
+        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0,
+                                                               0x7F7F7F7F, 0, 0x7F7F7F7F);
+      };
+      auto fold = [&](int nb, int mb, const f32x16g& part, float s) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nb][mb][r] += s * part[r];
+        asm volatile("" : "+v"(acc[nb][mb]));  // IR-level sinking ignores sched_barrier: pin the fold here
+      };
+      const float s0 = sa[0] * sb, s1 = sa[1] * sb;
+      i32x8g fa0[2], fa1[2], fb0[2], fb1[2];
+      // The two MFMAs of a block are dependent (same accumulator): the second cannot issue for the 64 cycles
+      // the first one runs, and neither can anything behind it in this wave.  So the previous block's fold
+      // sits BETWEEN the two, in the shadow of the first.
+      // region 0: fragment reads, the fold carried over from the previous k step hides their latency
+      fa0[0] = frag(a_rd_base, 0, 0);
+      fb0[0] = frag(b_rd_base, 0, 0);
+      fa0[1] = frag(a_rd_base, 1, 0);
+      fb0[1] = frag(b_rd_base, 1, 0);
+      fa1[0] = frag(a_rd_base, 0, 1);
+      fa1[1] = frag(a_rd_base, 1, 1);
+      fold(1, 1, p_carry, s_carry);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x16g p00 = mfma0(fb0[0], fa0[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      fb1[0] = frag(b_rd_base, 0, 1);
+      fb1[1] = frag(b_rd_base, 1, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      p00 = mfma1(fb0[1], fa0[1], p00);
+      // region 1
+      f32x16g p01 = mfma0(fb0[0], fa1[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(0, 0, p00, s0);
+      __builtin_amdgcn_sched_barrier(0);
+      p01 = mfma1(fb0[1], fa1[1], p01);
+      // region 2
+      f32x16g p10 = mfma0(fb1[0], fa0[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(0, 1, p01, s1);
+      __builtin_amdgcn_sched_barrier(0);
+      p10 = mfma1(fb1[1], fa0[1], p10);
+      // region 3
+      f32x16g p11 = mfma0(fb1[0], fa1[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      fold(1, 0, p10, s0);
+      __builtin_amdgcn_sched_barrier(0);
+      p11 = mfma1(fb1[1], fa1[1], p11);
+      p_carry = p11;
+      s_carry = s1;
+      // D(kb + 1) must have landed (all waves' pieces: barrier); the 8 pieces of D(kb + 2) stay in flight
+      if (kb + 2 < kblocks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);  // no mixing of two k steps either
+    };
+    {
+      int kb = 0;
+      for (; kb + 2 < kblocks; kb += 3) {
+        k_step(std::integral_constant<int, 0>{}, kb);
+        k_step(std::integral_constant<int, 1>{}, kb + 1);
+        k_step(std::integral_constant<int, 2>{}, kb + 2);
+      }
+      if (kb < kblocks) k_step(std::integral_constant<int, 0>{}, kb);
+      if (kb + 1 < kblocks) k_step(std::integral_constant<int, 1>{}, kb + 1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[1][1][r] += s_carry * p_carry[r];
+  }
+  if (have_out) store_tile();
+}
+
 static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int grid = p.num_m_tiles_bound * p.n_tiles;
   if (grid <= 0) return hipSuccess;
@@ -644,6 +922,21 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int ws_tiles = p.num_m_tiles_bound_ws * p.n_tiles;
   const int ws_grid = (fi_num_compute_units() / 8) * 8;  // persistent: one workgroup per CU, XCD-aligned
   const bool use_ws = use_mx && ws_min_tiles >= 0 && ws_tiles >= ws_min_tiles && ws_grid >= 8;
+  static const bool use_dma = [] {
+    const char* e = getenv("FI_GEMM_DMA");  // 0: the register-staged 256 x 128 kernel
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (use_ws && use_dma) {
+    GemmParams q = p;
+    q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
+    switch (sel) {
+      case 0: group_gemm_fp8_dma_kernel<false, false><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      case 1: group_gemm_fp8_dma_kernel<false, true><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      case 2: group_gemm_fp8_dma_kernel<true, false><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      default: group_gemm_fp8_dma_kernel<true, true><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+    }
+    return hipGetLastError();
+  }
   if (use_ws) {
     GemmParams q = p;
     q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
