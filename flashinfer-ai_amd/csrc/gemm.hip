@@ -44,6 +44,41 @@ struct GemmParams {
 
 using f32x16g = __attribute__((ext_vector_type(16))) float;
 
+// (group, m tile) of the mt_global-th m tile from the running count of tiles per group, on the device (the
+// reference's arg-prep kernel group_gemm_fp8_groupwise_sm100.cuh:35-72 also sizes the groups on the device, no
+// host sync).  Wave-parallel: 64 groups per pass -- lane i loads m_indptr[i], [i + 1], an inclusive scan over
+// the lanes gives each group's first tile -- so that 256 experts cost 4 passes, not 256 dependent loads.
+// Every lane of every wave runs it with the same arguments and gets the same (uniform) answer.
+template <int TILE_M>
+__device__ __forceinline__ bool find_group_tile(const int32_t* m_indptr, int num_groups, int mt_global, int lane,
+                                                int& g, int& m_begin, int& m_end, int& mt) {
+  int first = 0;  // tiles in the groups of earlier passes
+  for (int base = 0; base < num_groups; base += 64) {
+    const int gi = base + lane;
+    const bool in = gi < num_groups;
+    const int lo = in ? m_indptr[gi] : 0, hi = in ? m_indptr[gi + 1] : 0;
+    const int tiles = (hi - lo + TILE_M - 1) / TILE_M;
+    int incl = tiles;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    const int start = first + incl - tiles;
+    const uint64_t hit = __ballot(in && mt_global >= start && mt_global < start + tiles);
+    if (hit) {
+      const int src = __builtin_ctzll(hit);
+      g = base + src;
+      m_begin = __builtin_amdgcn_readlane(lo, src);
+      m_end = __builtin_amdgcn_readlane(hi, src);
+      mt = mt_global - __builtin_amdgcn_readlane(start, src);
+      return true;
+    }
+    first += __builtin_amdgcn_readlane(incl, 63);
+  }
+  return false;
+}
+
 template <bool A_E5M2, bool B_E5M2>
 __device__ __forceinline__ f32x16g mfma_fp8(long a, long b, f32x16g c) {
   if constexpr (!A_E5M2 && !B_E5M2) return __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a, b, c, 0, 0, 0);
@@ -86,25 +121,9 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
   const int band_m = min(kBandM, p.num_m_tiles_bound - band * kBandM);
   const int nt = in_band / band_m;
   const int mt_global = band * kBandM + (in_band - nt * band_m);
-  // (group, m tile) from the running count of m tiles (ref: arg-prep kernel
-  // group_gemm_fp8_groupwise_sm100.cuh:35-72 computes per-group problem sizes on the device too)
   int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
   if (p.m_indptr) {
-    int acc = 0;
-    bool found = false;
-    for (int gi = 0; gi < p.num_groups; ++gi) {
-      const int lo = p.m_indptr[gi], hi = p.m_indptr[gi + 1];
-      const int tiles = (hi - lo + kBM - 1) / kBM;
-      if (!found && mt_global < acc + tiles) {
-        g = gi;
-        m_begin = lo;
-        m_end = hi;
-        mt = mt_global - acc;
-        found = true;
-      }
-      acc += tiles;
-    }
-    if (!found) return;
+    if (!find_group_tile<kBM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt)) return;
   } else if (mt_global * kBM >= p.m_total) {
     return;
   }
@@ -431,20 +450,7 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(cons
     int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
     bool found = true;
     if (p.m_indptr) {
-      int cnt = 0;
-      found = false;
-      for (int gi = 0; gi < p.num_groups; ++gi) {
-        const int lo = p.m_indptr[gi], hi = p.m_indptr[gi + 1];
-        const int tiles = (hi - lo + kWsBM - 1) / kWsBM;
-        if (!found && mt_global < cnt + tiles) {
-          g = gi;
-          m_begin = lo;
-          m_end = hi;
-          mt = mt_global - cnt;
-          found = true;
-        }
-        cnt += tiles;
-      }
+      found = find_group_tile<kWsBM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
     } else if (mt_global * kWsBM >= p.m_total) {
       found = false;
     }
@@ -726,20 +732,7 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
     int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
     bool found = true;
     if (p.m_indptr) {
-      int cnt = 0;
-      found = false;
-      for (int gi = 0; gi < p.num_groups; ++gi) {
-        const int lo = p.m_indptr[gi], hi = p.m_indptr[gi + 1];
-        const int tiles = (hi - lo + kWsBM - 1) / kWsBM;
-        if (!found && mt_global < cnt + tiles) {
-          g = gi;
-          m_begin = lo;
-          m_end = hi;
-          mt = mt_global - cnt;
-          found = true;
-        }
-        cnt += tiles;
-      }
+      found = find_group_tile<kWsBM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
     } else if (mt_global * kWsBM >= p.m_total) {
       found = false;
     }

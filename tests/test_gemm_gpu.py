@@ -114,7 +114,10 @@ def test_gemm_errors():
                                     # >= 2 x CUs tiles of 256 x 128: the persistent 256 x 128 kernel (ragged groups,
                                     # an empty group, a partial n tile; odd / even k block counts, one k block)
                                     ([2300, 4, 0, 3100, 1000, 777], 2696, 256), ([8000], 2056, 384),
-                                    ([255, 257, 6000, 1], 3584, 128)])
+                                    ([255, 257, 6000, 1], 3584, 128),
+                                    # more than 64 groups (two passes of the wave-parallel group search), empty
+                                    # groups in between
+                                    ([(37 * i) % 301 if i % 5 else 0 for i in range(150)], 264, 128)])
 def test_group_gemm_exact_many_tiles_banded_order(ms, n, k):
     """More m tiles than one band and a ragged last band / last n tile: every (group, m tile, n tile) must
     be visited exactly once by the banded tile order of either kernel.  Small integers -> the result is exact."""

@@ -24,3 +24,4 @@ if __name__ == "__main__":
     run(tag="C4")
     run(g=1, m=8192, n=8192, k=8192, tag="square 8k")
     run(g=8, m=512, n=4096, k=7168, tag="moe small m")
+    run(g=256, m=128, n=4096, k=7168, tag="256 experts")
