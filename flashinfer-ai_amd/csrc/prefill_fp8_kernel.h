@@ -25,6 +25,9 @@
 
 #include "prefill_kernel.h"
 
+#ifndef FI_PF8_KO
+#define FI_PF8_KO 0  // experiments only, bit mask: 1 no K/V loads and LDS stores in the tile loop, 2 no exp2 in the softmax
+#endif
 namespace fi {
 
 using i32x8 = __attribute__((ext_vector_type(8))) int;
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
       // each, get spilled, and every reload (a VMEM op) drags a vmcnt(0) wait -- on the K/V loads just
       // issued -- into the MFMA section
       asm volatile("" : "+v"(k_rd_base), "+v"(v_rd_base));
-      issue_loads((t + 1) & 3, st);
+      if (!(FI_PF8_KO & 1)) issue_loads((t + 1) & 3, st);
       const bool tab_wave = wave == (t & 3);
       int tab_pg = 0, tab_en = 0;
       if (tab_wave) tab_lookup(tile_base + min(t + 2, num_tiles - 1), tab_pg, tab_en);
@@ -286,7 +289,8 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_adj));
+          s_acc[kbk][r] = (FI_PF8_KO & 2) ? __builtin_fmaf(s_acc[kbk][r], c_log2, -m_adj)
+                                          : fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_adj));
           psum += s_acc[kbk][r];
         }
       l_run = l_run * alpha + psum;
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
         o_acc[db] = mfma_fp8_k64(a, p8, o_acc[db]);
       }
 
-      write_stage(buf ^ 1, st);
+      if (!(FI_PF8_KO & 1)) write_stage(buf ^ 1, st);
       if (tab_wave) tab_store((t + 2) & 3, tab_pg, tab_en);
       __syncthreads();
     };
