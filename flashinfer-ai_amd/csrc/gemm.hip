@@ -681,17 +681,17 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
   int out_m0 = 0, out_n0 = 0, out_m_end = 0;  // tile whose accumulators are waiting to be stored
   bool have_out = false;
   // Output: the accumulators are transposed (m on the lane), so a direct store writes 8-byte pieces.  Each
-  // wave instead turns its 64 x 64 block through its own 9 KB of LDS ([m][64 n] bf16/f16 rows, 144-byte row
-  // stride) and stores whole 128-byte rows, 16 bytes per lane.  Callers put a workgroup barrier between this
-  // and the next LDS stage store.
-  constexpr int kOutStride = 144;
+  // wave instead turns its 64 x 64 block, one 32-column half at a time, through 5 KB of LDS stage 2 -- free at
+  // a tile border while the next tile's first two blocks are already landing in stages 0 and 1 -- and stores
+  // 64-byte row pieces, 16 bytes per lane.
+  constexpr int kOutStride = 80;
   const bool d_aligned16 = (((uintptr_t)p.d) & 15) == 0;
   auto store_tile = [&]() {
-    uint8_t* const scratch = &smem[0][0] + wave * (64 * kOutStride);
+    uint8_t* const scratch = &smem[2][0] + wave * (64 * kOutStride);
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
           uint32_t w[2];
@@ -701,22 +701,23 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
             const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
             w[e] = lo | (hi << 16);
           }
-          *(u32x2*)(scratch + (32 * mb + lq) * kOutStride + (32 * nb + 8 * r4 + 4 * lh) * 2) = u32x2{w[0], w[1]};
+          *(u32x2*)(scratch + (32 * mb + lq) * kOutStride + (8 * r4 + 4 * lh) * 2) = u32x2{w[0], w[1]};
         }
 #pragma unroll
-    for (int i2 = 0; i2 < 8; ++i2) {
-      const int idx = lane + 64 * i2;
-      const int r = idx >> 3, c = idx & 7;
-      const u32x4 v = *(const u32x4*)(scratch + r * kOutStride + c * 16);
-      const int m = out_m0 + 64 * wm + r;
-      const int n = out_n0 + 64 * wn + 8 * c;
-      if (m >= out_m_end || n >= N) continue;  // n is a multiple of 8 and so is N
-      uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
-      if (d_aligned16) {
-        *(u32x4*)dst = v;
-      } else {
-        *(u32x2*)dst = u32x2{v[0], v[1]};
-        *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};
+      for (int i2 = 0; i2 < 4; ++i2) {
+        const int idx = lane + 64 * i2;
+        const int r = idx >> 2, c = idx & 3;
+        const u32x4 v = *(const u32x4*)(scratch + r * kOutStride + c * 16);
+        const int m = out_m0 + 64 * wm + r;
+        const int n = out_n0 + 64 * wn + 32 * nb + 8 * c;
+        if (m >= out_m_end || n >= N) continue;  // n is a multiple of 8 and so is N
+        uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
+        if (d_aligned16) {
+          *(u32x4*)dst = v;
+        } else {
+          *(u32x2*)dst = u32x2{v[0], v[1]};
+          *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};
+        }
       }
     }
   };
@@ -781,25 +782,27 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_sc + (int64_t)kb * b_sc_stride),
                                        (__attribute__((address_space(3))) void*)(&smem[stage][kScOff + wave * 512 + 256]), 4, 0, 0);
     };
-    if (have_out) {
-      store_tile();
-      __syncthreads();  // the transposition scratch overlaps the LDS stages
-    }
+    // the next tile's first two blocks go out BEFORE the finished tile is converted and stored (stages 0
+    // and 1; the store's scratch is stage 2): with one workgroup per CU nothing else would cover the round trip
+    dma(0, 0);
+    if (kblocks > 1) dma(1, 1);
+    const bool stored = have_out;
+    if (have_out) store_tile();
     out_m0 = m0;
     out_n0 = n0;
     out_m_end = m_end;
     have_out = true;
-    dma(0, 0);
-    if (kblocks > 1) dma(1, 1);
 #pragma unroll
     for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
       for (int j2 = 0; j2 < 2; ++j2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i2][j2][r] = 0.f;
-    if (kblocks > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // D(0) landed, D(1) (8 pieces) in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // D(0) landed.  The output stores are younger than both blocks and vmcnt retires in order, so with
+    // stores in the queue the only count that is sure to cover D(0) is 0.
+    if (kblocks > 1 && !stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // also: every wave is done with the stage 2 scratch before step 0's DMA
     f32x16g p_carry;  // block (1, 1) of the previous k step, folded at the start of the next one
 #pragma unroll
     for (int r = 0; r < 16; ++r) p_carry[r] = 0.f;
