@@ -639,17 +639,23 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(cons
 // VGPR -> LDS store transfer.  Synchronisation is by hand: every wave waits `vmcnt(8)` (its own pieces of the
 // NEXT block landed, the 8 DMA instructions of the block after it still in flight) and then a raw `s_barrier`
 // -- `__syncthreads()` would drain vmcnt.  FI_GEMM_DMA=0 selects the register-staged kernel above.
-template <bool MA_E5M2, bool MB_E5M2>
+template <bool MA_E5M2, bool MB_E5M2, int TM>
 __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const GemmParams p) {
+  // TM x TN output tile, TM + TN = 384 rows of operands per k block: 256 x 128, or 128 x 256 for groups of few
+  // rows (a group of <= 128 rows wastes half of a 256-row tile, and B -- streamed once from HBM when every group
+  // has a single m tile -- gets twice the bytes in flight)
+  constexpr int TN = kWsBM + kBN - TM;
+  constexpr int WM = TM / 64;  // waves along m; 8 / WM along n
+  static_assert(TM == 256 || TM == 128, "tile");
   // [stage][A 32 KB | B 16 KB | per wave: 64 A scales, 64 x the B scale]  (one array: the compiler tells a DMA
   // target from an LDS read by constant offsets inside ONE object; a second array made it wait vmcnt(0))
   constexpr int kScOff = (kWsBM + kBN) * kBK;
   __shared__ __attribute__((aligned(1024))) uint8_t smem[3][kScOff + (kWsThreads / 64) * 512];
-  constexpr int kBOff = kWsBM * kBK;
+  constexpr int kBOff = TM * kBK;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WM, wn = wave / WM;
   const int lq = lane & 31, lh = lane >> 5;
   const int K = p.k, N = p.n;
   const int kblocks = K / kBK;
@@ -665,7 +671,8 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
   uint32_t b_rd_base = (uint32_t)(kBOff + lds_off(64 * wn + lq, 2 * lh));
 
   // ---- persistent workgroup: the XCD-contiguous tile range of this XCD, strided by its workgroups ----
-  const int total = p.num_m_tiles_bound * p.n_tiles;
+  const int n_tiles = (N + TN - 1) / TN;
+  const int total = p.num_m_tiles_bound * n_tiles;
   int logical, logical_end;
   const int logical_step = gridDim.x >> 3;
   {
@@ -723,8 +730,8 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
   };
 
   for (; logical < logical_end; logical += logical_step) {
-    constexpr int kBandM = 4;  // 1024 rows x all n per band, as in the 128 x 128 kernel
-    const int band_tiles = kBandM * p.n_tiles;
+    constexpr int kBandM = 1024 / TM;  // 1024 rows x all n per band, as in the 128 x 128 kernel
+    const int band_tiles = kBandM * n_tiles;
     const int band = logical / band_tiles;
     const int in_band = logical - band * band_tiles;
     const int band_m = min(kBandM, p.num_m_tiles_bound - band * kBandM);
@@ -733,13 +740,13 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
     int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
     bool found = true;
     if (p.m_indptr) {
-      found = find_group_tile<kWsBM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
-    } else if (mt_global * kWsBM >= p.m_total) {
+      found = find_group_tile<TM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
+    } else if (mt_global * TM >= p.m_total) {
       found = false;
     }
     if (!found) continue;  // the grid bound counts one partial tile per group; uniform per workgroup
-    const int m0 = m_begin + mt * kWsBM;
-    const int n0 = nt * kBN;
+    const int m0 = m_begin + mt * TM;
+    const int n0 = nt * TN;
     const uint8_t* Bg = p.b + (int64_t)g * N * K;
 
     // LDS-DMA geometry: the stage image is [384 rows][128 B] (A rows 0-255, B rows 256-383) and a piece =
@@ -753,12 +760,13 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
     for (int j2 = 0; j2 < 6; ++j2) {
       const int row = 8 * (6 * wave + j2) + (lane >> 3);
       const int ch = (lane & 7) ^ ((row >> 1) & 7);
-      const int r = row < kWsBM ? min(m0 + row, m_end - 1) - m0 : min(n0 + row - kWsBM, N - 1) - n0;
+      const int r = row < TM ? min(m0 + row, m_end - 1) - m0 : min(n0 + row - TM, N - 1) - n0;
       d_off[j2] = (uint32_t)r * (uint32_t)K + ch * 16;
     }
     // scale sources for the DMA: one A-scale pointer per lane (row 64 wm + lane of the tile), B scale uniform
-    const float* const b_sc = p.scale_k_major ? p.b_scale + ((int64_t)g * n_sblocks + n0 / 128) * kblocks
-                                              : p.b_scale + (int64_t)g * kblocks * n_sblocks + n0 / 128;
+    const int nsb = min((n0 + 64 * wn) / 128, n_sblocks - 1);  // this wave's 128-wide scale block of B
+    const float* const b_sc = p.scale_k_major ? p.b_scale + ((int64_t)g * n_sblocks + nsb) * kblocks
+                                              : p.b_scale + (int64_t)g * kblocks * n_sblocks + nsb;
     const float* a_sc_dma;
     {
       const int m = min(m0 + 64 * wm + lane, m_end - 1);
@@ -770,7 +778,7 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
 #pragma unroll
       for (int j2 = 0; j2 < 6; ++j2) {
         const int q = 6 * wave + j2;
-        const uint8_t* src_p = (q < kWsBM / 8 ? a_tile : b_tile) + (d_off[j2] + koff);
+        const uint8_t* src_p = (q < TM / 8 ? a_tile : b_tile) + (d_off[j2] + koff);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_p,
                                          (__attribute__((address_space(3))) void*)(&smem[stage][q * 1024]), 16, 0, 0);
       }
@@ -922,14 +930,32 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     const char* e = getenv("FI_GEMM_DMA");  // 0: the register-staged 256 x 128 kernel
     return e ? atoi(e) != 0 : true;
   }();
+  // 128 x 256 tiles for grouped problems whose groups have few rows (a <= 128-row group fills half of a
+  // 256-row tile); FI_GEMM_DMA_TM = 128 / 256 forces the shape
+  static const int forced_tm = [] {
+    const char* e = getenv("FI_GEMM_DMA_TM");
+    return e ? atoi(e) : 0;
+  }();
+  const bool few_rows = p.m_indptr != nullptr && p.m_total <= 160 * (int64_t)p.num_groups;
+  const bool tall = forced_tm == 128 || (forced_tm != 256 && few_rows);
+  const int tall_tiles = p.num_m_tiles_bound * ceil_div(p.n, 2 * kBN);
+  if (use_dma && use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && tall && tall_tiles >= ws_min_tiles) {
+    switch (sel) {  // num_m_tiles_bound already counts 128-row tiles
+      case 0: group_gemm_fp8_dma_kernel<false, false, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+      case 1: group_gemm_fp8_dma_kernel<false, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+      case 2: group_gemm_fp8_dma_kernel<true, false, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+      default: group_gemm_fp8_dma_kernel<true, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+    }
+    return hipGetLastError();
+  }
   if (use_ws && use_dma) {
     GemmParams q = p;
     q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
     switch (sel) {
-      case 0: group_gemm_fp8_dma_kernel<false, false><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-      case 1: group_gemm_fp8_dma_kernel<false, true><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-      case 2: group_gemm_fp8_dma_kernel<true, false><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-      default: group_gemm_fp8_dma_kernel<true, true><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      case 0: group_gemm_fp8_dma_kernel<false, false, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      case 1: group_gemm_fp8_dma_kernel<false, true, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      case 2: group_gemm_fp8_dma_kernel<true, false, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
+      default: group_gemm_fp8_dma_kernel<true, true, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
     }
     return hipGetLastError();
   }

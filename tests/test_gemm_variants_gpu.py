@@ -2,7 +2,8 @@
 
 The library picks the kernel by problem size (256 x 128 persistent kernels from 2 x CUs tiles on) and reads its
 switches once per process, so the forced variants run in a child process:
-  FI_GEMM_WS_MIN_TILES=0            -> every shape takes the persistent LDS-DMA kernel
+  FI_GEMM_WS_MIN_TILES=0 FI_GEMM_DMA_TM=256 / 128 -> every shape takes the persistent LDS-DMA kernel with
+                                       256 x 128 / 128 x 256 tiles
   FI_GEMM_WS_MIN_TILES=0 FI_GEMM_DMA=0 -> ... the persistent register-staged kernel
 (the default run of test_gemm_gpu.py covers the 128 x 128 kernel and the size-based choice)."""
 import os
@@ -15,8 +16,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env", [{"FI_GEMM_WS_MIN_TILES": "0"}, {"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA": "0"}],
-                         ids=["dma", "register-staged"])
+@pytest.mark.parametrize("env", [{"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA_TM": "256"},
+                                 {"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA_TM": "128"},
+                                 {"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA": "0"}],
+                         ids=["dma-256x128", "dma-128x256", "register-staged"])
 def test_gemm_suite_through_forced_kernel(env):
     child_env = dict(os.environ)
     child_env.update(env)
