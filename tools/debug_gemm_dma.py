@@ -1,4 +1,5 @@
-"""Compare the LDS-DMA GEMM variant (FI_GEMM_DMA=1) with the exact small-integer result; prints where they differ."""
+"""Compare a forced GEMM kernel (FI_GEMM_WS_MIN_TILES=0 with FI_GEMM_DMA / FI_GEMM_DMA_TM) with the exact
+small-integer result rounded to fp16; prints where they differ."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flashinfer-ai_amd"))
@@ -17,7 +18,7 @@ for (m, n, k) in [(4, 1032, 256), (4, 1024, 256), (4, 256, 256), (300, 1032, 384
     for kb in range(k // 128):
         part = a[:, kb * 128:(kb + 1) * 128].double() @ b[:, kb * 128:(kb + 1) * 128].double().T
         ref += part * sa[kb, :, None].double() * sb[kb].double().repeat_interleave(128)[:n][None]
-    bad = (out != ref.float())
+    bad = (out != ref.float().half().float())
     print((m, n, k), "mismatches", int(bad.sum()), "of", bad.numel())
     if bad.any():
         rows = bad.any(1).nonzero().flatten().tolist()
