@@ -684,6 +684,25 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
     logical_end = start + qn + (xcd < rn ? 1 : 0);
   }
 
+  // Up to 64 groups: lane i keeps group i's row range and first tile for the whole kernel, so the per-tile
+  // (group, m tile) search is a ballot + three readlanes instead of loads (a round trip per tile, with
+  // nothing else in flight to hide it).  More groups: the looping search per tile.
+  const bool groups_cached = p.m_indptr != nullptr && p.num_groups <= 64;
+  int gc_lo = 0, gc_hi = 0, gc_start = 0;
+  if (groups_cached) {
+    const bool in = lane < p.num_groups;
+    gc_lo = in ? p.m_indptr[lane] : 0;
+    gc_hi = in ? p.m_indptr[lane + 1] : 0;
+    const int tiles = (gc_hi - gc_lo + TM - 1) / TM;
+    int incl = tiles;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += v;
+    }
+    gc_start = incl - tiles;
+  }
+
   f32x16g acc[2][2];  // [n block][m block]
   int out_m0 = 0, out_n0 = 0, out_m_end = 0;  // tile whose accumulators are waiting to be stored
   bool have_out = false;
@@ -740,7 +759,19 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
     int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
     bool found = true;
     if (p.m_indptr) {
-      found = find_group_tile<TM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
+      if (groups_cached) {
+        const int tiles = (gc_hi - gc_lo + TM - 1) / TM;
+        const uint64_t hit = __ballot(mt_global >= gc_start && mt_global < gc_start + tiles);
+        found = hit != 0;
+        if (found) {
+          g = __builtin_ctzll(hit);
+          m_begin = __builtin_amdgcn_readlane(gc_lo, g);
+          m_end = __builtin_amdgcn_readlane(gc_hi, g);
+          mt = mt_global - __builtin_amdgcn_readlane(gc_start, g);
+        }
+      } else {
+        found = find_group_tile<TM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
+      }
     } else if (mt_global * TM >= p.m_total) {
       found = false;
     }
