@@ -141,3 +141,43 @@ def test_group_gemm_exact_many_tiles_banded_order(ms, n, k):
             ref[lo:hi] += part * sa[kb, lo:hi, None].double() * sb[gi, kb].double().repeat_interleave(128)[:n][None]
     assert ref.abs().max() < 60000
     torch.testing.assert_close(out.float().cpu(), ref.float().half().float(), atol=0, rtol=0)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_group_gemm_random_shapes_exact(seed):
+    """Seeded random (groups, rows per group, n, k, scale layout, output type) with small-integer operands and
+    power-of-two scales: the result is exact, whichever kernel / tile shape the size-based dispatch picks."""
+    import random
+
+    import flashinfer
+
+    rng = random.Random(1000 + seed)
+    torch.manual_seed(1000 + seed)
+    g = rng.choice([1, 2, 5, 8, 33, 70])
+    big = rng.random() < 0.5
+    ms = [rng.choice([0, 1, 7, 64, 128, 129, 255, 256, 300]) * (rng.choice([1, 4, 9]) if big else 1) for _ in range(g)]
+    if sum(ms) == 0:
+        ms[0] = 5
+    n = 8 * rng.randint(1, 380 if big else 40)
+    k = 128 * rng.randint(1, 5)
+    mode = rng.choice(["MN", "K"])
+    out_dtype = rng.choice([torch.float16, torch.bfloat16])
+    cum = sum(ms)
+    lim = 3 if out_dtype == torch.float16 else 1  # keep every partial sum exactly representable in the output type
+    a = torch.randint(-lim, lim + 1, (cum, k)).float()
+    b = torch.randint(-1, 2, (g, n, k)).float()
+    sa = torch.pow(2.0, torch.randint(-1, 1, (k // 128, cum)).float())
+    sb = torch.pow(2.0, torch.randint(-1, 1, (g, k // 128, -(-n // 128))).float())
+    m_indptr = torch.tensor([0] + list(torch.tensor(ms).cumsum(0)), dtype=torch.int32)
+    sa_dev = sa if mode == "MN" else sa.t().contiguous()
+    sb_dev = sb if mode == "MN" else sb.permute(0, 2, 1).contiguous()
+    out = flashinfer.group_gemm_fp8_nt_groupwise(a.to(torch.float8_e4m3fn).to(DEV), b.to(torch.float8_e4m3fn).to(DEV),
+                                                 sa_dev.to(DEV), sb_dev.to(DEV), m_indptr.to(DEV), scale_major_mode=mode,
+                                                 out_dtype=out_dtype)
+    ref = torch.zeros(cum, n, dtype=torch.float64)
+    for gi in range(g):
+        lo, hi = int(m_indptr[gi]), int(m_indptr[gi + 1])
+        for kb in range(k // 128):
+            part = a[lo:hi, kb * 128:(kb + 1) * 128].double() @ b[gi, :, kb * 128:(kb + 1) * 128].double().T
+            ref[lo:hi] += part * sa[kb, lo:hi, None].double() * sb[gi, kb].double().repeat_interleave(128)[:n][None]
+    torch.testing.assert_close(out.float().cpu(), ref.float().to(out_dtype).float(), atol=0, rtol=0)
