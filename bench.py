@@ -94,18 +94,76 @@ def cpu_baseline(cfg, sample_requests=8, iters=3):
     }
 
 
-def _time_ms(fn, iters, warm):
+_L2_FLUSH = {}
+
+
+def _time_ms(fn, iters, warm, flush_l2=True):
+    """median of `iters` event-bracketed launches; the 256 MB buffer written before each one evicts L2 /
+    Infinity Cache as the reference's bench does (flashinfer/testing/utils.py:544-545)."""
+    dev = torch.cuda.current_device()
+    if flush_l2 and dev not in _L2_FLUSH:
+        _L2_FLUSH[dev] = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
     for s, e in ev:
+        if flush_l2:
+            _L2_FLUSH[dev].zero_()
         s.record()
         fn()
         e.record()
     torch.cuda.synchronize()
     ts = sorted(s.elapsed_time(e) for s, e in ev)
     return ts[len(ts) // 2]
+
+
+def cpu_baseline_c3(b, qo, kv, hq, hkv, d, sample_heads=8, iters=1):
+    """torch-CPU SDPA (fp32, explicit bottom-right causal mask) on ONE request and `sample_heads` of the q heads
+    of C3's shape; FLOPs counted with the same causal formula."""
+    import torch.nn.functional as F
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    group = hq // hkv
+    q = torch.randn(1, sample_heads, qo, d, generator=g)
+    k = torch.randn(1, sample_heads // group, kv, d, generator=g)
+    v = torch.randn(1, sample_heads // group, kv, d, generator=g)
+    mask = torch.ones(qo, kv, dtype=torch.bool).tril(kv - qo)
+    ts = []
+    for _ in range(iters + 1):  # first run warms the allocator / thread pool
+        t0 = time.perf_counter()
+        F.scaled_dot_product_attention(q, k, v, attn_mask=mask, enable_gqa=True)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts[1:])
+    flops = (2 * kv - qo) * qo * sample_heads * 2 * d
+    return {"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {b} requests, {sample_heads} of {hq} q heads (qo {qo}, kv {kv}, d {d}, causal), fp32 "
+                      f"torch-CPU SDPA on dequantised values, {t * 1e3:.0f} ms"}
+
+
+def cpu_baseline_c4(G, m, n, k, sample_rows=512):
+    """dequantise -> fp32 torch.matmul on the host for `sample_rows` rows of ONE group of C4."""
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(sample_rows, k, generator=g).to(torch.float8_e4m3fn)
+    bm = (torch.randn(n, k, generator=g) / k ** 0.5).to(torch.float8_e4m3fn)
+    sa = torch.rand(k // 128, sample_rows, generator=g) + 0.5
+    sb = torch.rand(k // 128, n // 128, generator=g) + 0.5
+    ts = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        ad = a.float() * sa.t().repeat_interleave(128, 1)
+        bd = bm.float() * sb.t().repeat_interleave(128, 0).repeat_interleave(128, 1)
+        torch.matmul(ad, bd.t())
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    flops = 2 * sample_rows * n * k
+    return {"value": flops / t / 1e12, "unit": "TFLOP/s", "cores": cores, "kind": "port",
+            "sample": f"{sample_rows} rows of 1 of {G} groups (n {n}, k {k}), dequantise + fp32 torch.matmul, "
+                      f"{t * 1e3:.0f} ms"}
 
 
 def secondary_workloads(device):
@@ -137,7 +195,8 @@ def secondary_workloads(device):
                             "head_dim=128 GQA 32/8 page_size=16", "ms": ms, "value": flops / ms / 1e9,
                 "unit": "TFLOP/s", "dtype": "fp8_e4m3",
                 "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 5000.0, "unit": "TFLOP/s",
-                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::batch_prefill_fp8_kernel"}})
+                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::batch_prefill_fp8_kernel"},
+                "l2_flush_between_iters": True, "cpu_baseline": cpu_baseline_c3(b, qo, kv, hq, hkv, d)})
     del cache, q, o, w, ws
     # C4: 8 experts, M=4096 per expert, N=14336, K=4096, 128-wide block scales
     G, m, n, k = 8, 4096, 14336, 4096
@@ -152,8 +211,86 @@ def secondary_workloads(device):
     out.append({"workload": "C4: group_gemm_fp8_nt_groupwise 8 experts M=4096 N=14336 K=4096 block=128", "ms": ms,
                 "value": flops / ms / 1e9, "unit": "TFLOP/s", "dtype": "fp8_e4m3",
                 "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 5000.0, "unit": "TFLOP/s",
-                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::group_gemm_fp8_dma_kernel"}})
+                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::group_gemm_fp8_dma_kernel"},
+                "l2_flush_between_iters": True, "cpu_baseline": cpu_baseline_c4(G, m, n, k)})
     return out
+
+
+def c5_cascade(device, world, rank, dist, iters=200, warm=30):
+    """BASELINE config C5 on the ranks of this job: cascade shared-prefix batch decode, 64 requests per GPU
+    (512 on 8), bf16 GQA 32/8 d128 page 16, shared prefix 8192 tokens + 128 unique tokens per request
+    (SURVEY.md 8d).  Two arrangements, both timed with a barrier + synchronize on either side, max over ranks:
+      sharded    : prefix pages split over the ranks; every rank attends ALL queries over its shard (prefill
+                   kernel, one request of world * 64 rows), states exchanged by ONE RCCL all_to_all_single and
+                   merged locally (flashinfer/distributed.py);
+      replicated : every rank holds the whole prefix and attends its own 64 queries, no communication (the
+                   scaling upper bound SURVEY.md 8e asks for beside it)."""
+    import flashinfer
+    from flashinfer import distributed as fdist
+
+    B, HQ, HKV, D, PS, PREFIX, UNIQUE = 64, 32, 8, 128, 16, 8192, 128
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    u_pages = UNIQUE // PS
+    cache_u = torch.randn(B * u_pages, 2, PS, HKV, D, device=device, dtype=torch.bfloat16, generator=g)
+    q_local = torch.randn(B, HQ, D, device=device, dtype=torch.bfloat16, generator=g)
+    dw = flashinfer.BatchDecodeWithPagedKVCacheWrapper(torch.zeros(64 << 20, dtype=torch.uint8, device=device), "NHD")
+    dw.plan((torch.arange(B + 1, dtype=torch.int32) * u_pages).to(device),
+            torch.randperm(B * u_pages, device=device, generator=g).to(torch.int32),
+            torch.full((B,), PS, dtype=torch.int32, device=device), HQ, HKV, D, PS, q_data_type=torch.bfloat16)
+
+    def prefix_wrapper(tokens, rows):
+        pages = tokens // PS
+        cache = torch.randn(pages, 2, PS, HKV, D, device=device, dtype=torch.bfloat16, generator=g)
+        w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(torch.zeros(128 << 20, dtype=torch.uint8, device=device), "NHD")
+        w.plan(torch.tensor([0, rows], dtype=torch.int32, device=device),
+               torch.tensor([0, pages], dtype=torch.int32, device=device),
+               torch.arange(pages, dtype=torch.int32, device=device),
+               torch.tensor([PS], dtype=torch.int32, device=device), HQ, HKV, D, PS, causal=False,
+               q_data_type=torch.bfloat16)
+        return w, cache
+
+    ex = fdist.SharedPrefixExchange(HQ, D, torch.bfloat16, device, B, always_collective=True)
+    pw_s, cache_s = prefix_wrapper(PREFIX // world, B * world)
+    pw_r, cache_r = prefix_wrapper(PREFIX, B)
+
+    def sharded():
+        return fdist.sharded_shared_prefix_decode(
+            q_local, lambda qa: pw_s.run(qa, cache_s, return_lse=True), lambda ql: dw.run(ql, cache_u, return_lse=True),
+            flashinfer.merge_states, flashinfer.merge_state, exchange=ex)
+
+    def replicated():
+        v_p, s_p = pw_r.run(q_local, cache_r, return_lse=True)
+        v_u, s_u = dw.run(q_local, cache_u, return_lse=True)
+        return flashinfer.merge_state(v_p, s_p, v_u, s_u)[0]
+
+    res = {}
+    for name, fn in (("sharded", sharded), ("replicated", replicated)):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[name] = float(t.item()) / iters
+    flat_bytes = 2 * B * (PREFIX + UNIQUE) * HKV * D * 2  # what a flat (non-cascade) decode reads per GPU
+    return {
+        "workload": f"C5: cascade shared-prefix batch decode bs={B * world} over {world} GPU(s) (64/GPU), bf16 GQA 32/8 "
+                    f"d128 page 16, prefix {PREFIX} + {UNIQUE} unique tokens",
+        "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
+        "collectives_per_step": "1 all_gather_into_tensor (q) + 1 all_to_all_single (packed v|lse states)",
+        "us_per_step_sharded_prefix": res["sharded"] * 1e6, "us_per_step_replicated_prefix": res["replicated"] * 1e6,
+        "requests_per_s_sharded": B * world / res["sharded"], "requests_per_s_replicated": B * world / res["replicated"],
+        "state_bytes_sent_per_rank_per_step": ex.bytes_sent_per_step,
+        "q_bytes_gathered_per_rank_per_step": (world - 1) * B * HQ * D * 2,
+        "flat_decode_equivalent_TBps_per_gpu": flat_bytes / res["sharded"] / 1e12,
+        "iters": iters,
+    }
 
 
 def main():
@@ -179,7 +316,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        import datetime
+
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))
 
     import flashinfer
 
@@ -223,13 +362,22 @@ def main():
     kernel_ms = sum(per_step) / args.steps
 
     nbytes, flops = algorithmic_bytes_flops(cfg)
+    c5 = None
+    if distributed:  # the one exchange step of the path (RCCL all-to-all of shared-prefix states), every rank
+        try:
+            c5 = c5_cascade(device, world, rank, dist)
+        except Exception as exc:
+            c5 = {"error": repr(exc)}
     if rank == 0:
         achieved = nbytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC passes (2 * FETCH_SIZE + WRITE_SIZE, gfx950 rule): NOT measured by
+        # this run -- a cached rocprofv3 result of the same config, labelled as such; dropped when the config differs
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "c2_decode_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and not args.no_permute:
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/c2_decode_traffic.json (rocprofv3 --pmc of this config, not this run)"
             except Exception:
                 traffic = None
         line = {
@@ -239,6 +387,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "setup_launches": 64,  # clock-ramp launches before the W warm-up steps (see main)
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
@@ -261,6 +410,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": "fi::batch_decode_kernel (+ merge_n_kernel)",
                 "kernel_ms": kernel_ms,
                 "kernel_ms_median": sorted(per_step)[len(per_step) // 2],
@@ -269,6 +419,8 @@ def main():
                 "algorithmic_bytes_per_launch": nbytes,
             },
         }
+        if c5 is not None:
+            line["c5"] = c5
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         if world == 1 and not args.no_secondary:

@@ -355,6 +355,8 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   kp.num_items = (int32_t)(padded * kv.num_kv_heads * kp.head_tiles);
   kp.kv_chunk_size = (int32_t)plan_info[FI_DP_KV_CHUNK_SIZE];
+  // the kernels read the chunk size from the slot plan() refreshes (graph replay after a re-plan)
+  kp.kv_chunk_size_ptr = (const int32_t*)(ib + plan_info[FI_DP_KV_CHUNK_SIZE_PTR_OFFSET]);
   kp.split_kv = split;
   kp.window_left = a->window_left;
   // chunks were cut from the window's pages at plan(): the kernel offsets them by the same first page

@@ -51,7 +51,10 @@ struct DecodeKernelParams {
   int32_t uniform_page;  // page_size is a power of two >= tokens per load: one page id per load
   int32_t fast_path;     // launch the FAST instantiation
   FastDiv page_div;
-  int32_t kv_chunk_size;  // tokens; only read when split_kv
+  int32_t kv_chunk_size;  // tokens; only read when split_kv and kv_chunk_size_ptr is null
+  // device copy of the chunk size in the int workspace: plan() rewrites it, so a captured run() replayed
+  // after a new plan() sees the new value (ref: *kv_chunk_size_ptr, decode.cuh:424, 926)
+  const int32_t* kv_chunk_size_ptr;
   int32_t split_kv;
   int32_t single_kv_len;  // used when indptr == nullptr
   int32_t window_left;    // < 0: off
@@ -310,8 +313,9 @@ struct DecodeWave {
       const int np = p.indptr[req + 1] - page_begin;
       chunk_base = np > 0 ? max((np - 1) * p.page_size - p.plan_window_left, 0) / p.page_size * p.page_size : 0;
     }
-    chunk_start = chunk_base + (p.split_kv ? kv_tile * p.kv_chunk_size : 0);
-    chunk_end = p.split_kv ? min(chunk_start + p.kv_chunk_size, kv_len) : kv_len;
+    const int kv_chunk_size = p.kv_chunk_size_ptr ? *p.kv_chunk_size_ptr : p.kv_chunk_size;
+    chunk_start = chunk_base + (p.split_kv ? kv_tile * kv_chunk_size : 0);
+    chunk_end = p.split_kv ? min(chunk_start + kv_chunk_size, kv_len) : kv_len;
     // sliding window (ref: variants.cuh:78-91 with qo_len = 1, qo_idx = 0):
     //   visible iff kv_idx + 1 + window_left >= kv_len
     win_start = p.window_left >= 0 ? max(0, kv_len - 1 - p.window_left) : 0;

@@ -80,8 +80,9 @@ __global__ void __launch_bounds__(kDecodeThreads, 2) decode_mfma_kernel(const De
     chunk_base = np > 0 ? max((np - 1) * p.page_size - p.plan_window_left, 0) / p.page_size * p.page_size : 0;
   }
   const int win_start = p.window_left >= 0 ? max(0, kv_len - 1 - p.window_left) : 0;
-  int chunk_start = chunk_base + (p.split_kv ? kv_tile * p.kv_chunk_size : 0);
-  const int chunk_end = p.split_kv ? min(chunk_start + p.kv_chunk_size, kv_len) : kv_len;
+  const int kv_chunk_size = p.kv_chunk_size_ptr ? *p.kv_chunk_size_ptr : p.kv_chunk_size;
+  int chunk_start = chunk_base + (p.split_kv ? kv_tile * kv_chunk_size : 0);
+  const int chunk_end = p.split_kv ? min(chunk_start + kv_chunk_size, kv_len) : kv_len;
   if (win_start > chunk_start) chunk_start += (win_start - chunk_start) / kDmTileKV * kDmTileKV;
   const int G = min(p.group_size - 32 * col_blk, 32);  // heads of this column block
   const int head0 = kv_head * p.group_size + 32 * col_blk;

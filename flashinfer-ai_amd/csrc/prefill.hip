@@ -134,7 +134,11 @@ extern "C" FI_API int fi_batch_prefill_plan(
         int64_t entries = 0;
         for (int b = 0; b < batch_size; ++b)
           entries += (int64_t)(qo_indptr_h[b + 1] - qo_indptr_h[b]) * ceil_div<int64_t>(kv_len[b], chunk);
-        return (entries * num_qo_heads * (head_dim_vo + 1) + 64) * (int64_t)sizeof(float);
+        int64_t lse_entries = entries;
+        if (enable_cuda_graph)  // the fixed lse region of a graph plan (below)
+          lse_entries = std::max(entries, std::max(items_at(chunk), std::max(max_items, graph_bound)) *
+                                              (ceil_div<int64_t>(kTileQ, group) + 1));
+        return (entries * num_qo_heads * head_dim_vo + lse_entries * num_qo_heads + 64) * (int64_t)sizeof(float);
       };
       while (kv_chunk < max_kv_len && ws_need(kv_chunk) > (int64_t)float_ws_bytes) kv_chunk *= 2;
     }
@@ -171,6 +175,7 @@ extern "C" FI_API int fi_batch_prefill_plan(
   const int64_t tile_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
   const int64_t kvt_off = ia.alloc(std::max<size_t>(padded, 1) * sizeof(int32_t));
   const int64_t mrg_off = ia.alloc((size_t)(nrows_tab + 1) * sizeof(int32_t));
+  const int64_t chunk_off = ia.alloc(sizeof(int32_t));
   FI_REQUIRE(ia.ok, "batch_prefill_plan: int workspace too small (%zu bytes)", int_ws_bytes);
   int32_t* req_h = (int32_t*)((char*)pinned_int_ws + req_off);
   int32_t* tile_h = (int32_t*)((char*)pinned_int_ws + tile_off);
@@ -181,6 +186,7 @@ extern "C" FI_API int fi_batch_prefill_plan(
     tile_h[i] = i < tile.size() ? tile[i] : 0;
     kvt_h[i] = i < kvt.size() ? kvt[i] : 0;
   }
+  *(int32_t*)((char*)pinned_int_ws + chunk_off) = (int32_t)kv_chunk;
   int64_t entries = 0;
   mrg_h[0] = 0;
   if (split_kv) {
@@ -197,9 +203,16 @@ extern "C" FI_API int fi_batch_prefill_plan(
   }
   int64_t v_off = 0, s_off = 0;
   if (split_kv) {
+    // lse region first, sized for the most partial states a launch of `padded` items can write (each
+    // (row, chunk) pair belongs to one item of <= kTileQ / G + 1 rows): with a fixed-shape (graph) plan
+    // both offsets are then the same for every plan, so a captured run() stays valid after a re-plan.
+    // The outputs follow and may use the rest of the workspace.
     OffsetAllocator fa(float_ws_bytes);
+    const int64_t rows_per_item = ceil_div<int64_t>(kTileQ, group) + 1;
+    const int64_t lse_entries =
+        enable_cuda_graph ? std::max<int64_t>(entries, (int64_t)padded * rows_per_item) : std::max<int64_t>(entries, 1);
+    s_off = fa.alloc((size_t)lse_entries * num_qo_heads * sizeof(float));
     v_off = fa.alloc((size_t)std::max<int64_t>(entries, 1) * num_qo_heads * head_dim_vo * sizeof(float));
-    s_off = fa.alloc((size_t)std::max<int64_t>(entries, 1) * num_qo_heads * sizeof(float));
     FI_REQUIRE(fa.ok, "batch_prefill_plan: float workspace too small (%zu bytes, need %zu for %lld partial "
                "states)", float_ws_bytes,
                (size_t)entries * num_qo_heads * (head_dim_vo + 1) * sizeof(float), (long long)entries);
@@ -207,6 +220,7 @@ extern "C" FI_API int fi_batch_prefill_plan(
   for (int i = 0; i < FI_PREFILL_PLAN_INFO_LEN; ++i) plan_info_out[i] = 0;
   plan_info_out[FI_PP_PADDED_BATCH_SIZE] = (int64_t)padded;
   plan_info_out[FI_PP_TOTAL_NUM_ROWS] = split_kv ? nrows_tab : total_num_rows;
+  plan_info_out[FI_PP_KV_CHUNK_SIZE_PTR_OFFSET] = chunk_off;
   plan_info_out[FI_PP_CTA_TILE_Q] = kTileQ;
   plan_info_out[FI_PP_REQUEST_INDICES_OFFSET] = req_off;
   plan_info_out[FI_PP_QO_TILE_INDICES_OFFSET] = tile_off;
@@ -300,13 +314,14 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   const bool split = plan_info[FI_PP_SPLIT_KV] != 0;
   if (split) {
     FI_REQUIRE(float_ws, "batch_prefill_paged_run: a split-kv plan needs the float workspace");
-    FI_REQUIRE((size_t)plan_info[FI_PP_S_OFFSET] <= float_ws_bytes,
+    FI_REQUIRE((size_t)plan_info[FI_PP_V_OFFSET] <= float_ws_bytes,
                "batch_prefill_paged_run: float workspace smaller than at plan()");
     kp.kv_tile_indices = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_KV_TILE_INDICES_OFFSET]);
     kp.merge_indptr = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_MERGE_INDPTR_OFFSET]);
     kp.tmp_o = (float*)((char*)float_ws + plan_info[FI_PP_V_OFFSET]);
     kp.tmp_lse = (float*)((char*)float_ws + plan_info[FI_PP_S_OFFSET]);
     kp.kv_chunk_size = (int32_t)plan_info[FI_PP_KV_CHUNK_SIZE];
+    kp.kv_chunk_size_ptr = (const int32_t*)((const char*)int_ws + plan_info[FI_PP_KV_CHUNK_SIZE_PTR_OFFSET]);
   }
   kp.alibi_slopes = a->alibi_slopes;
   kp.scale_q = a->scale_q;

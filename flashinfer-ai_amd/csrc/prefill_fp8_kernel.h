@@ -137,8 +137,9 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   }
   int kv_begin = 0;
   if (split) {  // split-KV work item (see prefill_kernel.h)
-    kv_begin = kv_chunk * p.kv_chunk_size;
-    kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
+    const int kv_chunk_size = p.kv_chunk_size_ptr ? *p.kv_chunk_size_ptr : p.kv_chunk_size;
+    kv_begin = kv_chunk * kv_chunk_size;
+    kv_end = min(kv_end, kv_begin + kv_chunk_size);
   }
   const int tile_base = kv_begin / kTileKV;
   const int num_tiles = kv_end > kv_begin ? (kv_end - kv_begin + kTileKV - 1) / kTileKV : 0;

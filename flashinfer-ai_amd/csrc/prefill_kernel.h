@@ -51,7 +51,10 @@ struct PrefillKernelParams {
   const int32_t* merge_indptr;     // [total qo rows + 1]
   float* tmp_o;
   float* tmp_lse;
-  int32_t kv_chunk_size;           // tokens, a multiple of the 64-row kv tile
+  int32_t kv_chunk_size;           // tokens, a multiple of the 64-row kv tile (used when the pointer is null)
+  // device copy of the chunk size in the int workspace, rewritten by every plan(): a captured run()
+  // replayed after a re-plan reads the current value (ref: *kv_chunk_size_ptr, prefill.cuh:2058)
+  const int32_t* kv_chunk_size_ptr;
   int32_t num_kv_chunks;           // single-request split (no work list): work = q tile * chunks + chunk
   const float* alibi_slopes;
   const float* scale_q;  // fp8: per qo head / kv head scales (NULL = 1)
@@ -320,8 +323,9 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     kv_begin = max(kv_len - qo_len + first_qo - p.window_left, 0) / kTileKV * kTileKV;
   }
   if (split) {
-    kv_begin += kv_chunk * p.kv_chunk_size;
-    kv_end = min(kv_end, kv_begin + p.kv_chunk_size);
+    const int kv_chunk_size = p.kv_chunk_size_ptr ? *p.kv_chunk_size_ptr : p.kv_chunk_size;
+    kv_begin += kv_chunk * kv_chunk_size;
+    kv_end = min(kv_end, kv_begin + kv_chunk_size);
   }
   const int tile_base = kv_begin / kTileKV;  // window starts and chunks sit on tile boundaries
   const int num_tiles = kv_end > kv_begin ? (kv_end - kv_begin + kTileKV - 1) / kTileKV : 0;

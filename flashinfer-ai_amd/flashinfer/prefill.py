@@ -38,7 +38,8 @@ def _scale_tensor(x, n: int, device) -> Optional[torch.Tensor]:
     if x is None:
         return None
     if not torch.is_tensor(x):
-        x = torch.full((n,), float(x), dtype=torch.float32)
+        # created on the device: no pageable host-to-device copy (which would sync, and fail under capture)
+        return torch.full((n,), float(x), dtype=torch.float32, device=device)
     x = x.to(device=device, dtype=torch.float32).contiguous()
     if x.numel() == 1 and n != 1:
         x = x.expand(n).contiguous()
@@ -154,9 +155,10 @@ def single_prefill_with_kv_cache(
     if is_float8(q):
         assert window_left == -1
         assert q.dtype == k.dtype == v.dtype
-        scale_q = _scale_tensor(1.0 if scale_q is None else scale_q, num_qo_heads, q.device)
-        scale_k = _scale_tensor(1.0 if scale_k is None else scale_k, num_kv_heads, q.device)
-        scale_v = _scale_tensor(1.0 if scale_v is None else scale_v, num_kv_heads, q.device)
+        # a missing scale is passed as NULL (= 1, include/fi_mi355.h): no tensor is created
+        scale_q = _scale_tensor(scale_q, num_qo_heads, q.device)
+        scale_k = _scale_tensor(scale_k, num_kv_heads, q.device)
+        scale_v = _scale_tensor(scale_v, num_kv_heads, q.device)
         if o_dtype is None:
             raise ValueError("o_dtype should be provided for FP8 attention")
     else:
@@ -523,15 +525,10 @@ class BatchPrefillWithPagedKVCacheWrapper:
             check_shape_dtype_device(out, out_shape, o_dtype, q.device, "out")
             if not out.is_contiguous():
                 raise ValueError("out must be contiguous")
-        fp8_q = is_float8(q)
-        if fp8_q:
-            scale_q = _scale_tensor(1.0 if scale_q is None else scale_q, self._num_qo_heads, q.device)
-            scale_k = _scale_tensor(1.0 if scale_k is None else scale_k, num_kv_heads, q.device)
-            scale_v = _scale_tensor(1.0 if scale_v is None else scale_v, num_kv_heads, q.device)
-        else:
-            scale_q = _scale_tensor(scale_q, self._num_qo_heads, q.device)
-            scale_k = _scale_tensor(scale_k, num_kv_heads, q.device)
-            scale_v = _scale_tensor(scale_v, num_kv_heads, q.device)
+        # missing scales are NULL pointers (= 1 in the kernels): run() creates no tensor and stays capturable
+        scale_q = _scale_tensor(scale_q, self._num_qo_heads, q.device)
+        scale_k = _scale_tensor(scale_k, num_kv_heads, q.device)
+        scale_v = _scale_tensor(scale_v, num_kv_heads, q.device)
         alibi = None
         if self._pos_encoding_mode == "ALIBI":
             alibi = _get_cache_alibi_slopes_buf(q.shape[1], q.device)

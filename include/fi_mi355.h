@@ -210,6 +210,7 @@ FI_API int fi_variable_length_merge_states(const void* v, const float* s, const 
 enum fi_prefill_plan_slot {
   FI_PP_PADDED_BATCH_SIZE = 0, /* work items launched (q tiles over all requests) */
   FI_PP_TOTAL_NUM_ROWS = 1,
+  FI_PP_KV_CHUNK_SIZE_PTR_OFFSET = 2, /* int workspace: int32 chunk size the kernels read (rewritten by plan) */
   FI_PP_CTA_TILE_Q = 3,
   FI_PP_REQUEST_INDICES_OFFSET = 4,
   FI_PP_QO_TILE_INDICES_OFFSET = 5,

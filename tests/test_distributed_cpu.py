@@ -20,7 +20,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, b_total=6):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -28,7 +28,7 @@ def _worker(rank, world, port, ret):
         from flashinfer import distributed as D
 
         torch.manual_seed(0)  # same global problem on every rank
-        b_total, hq, hkv, d, prefix_len, suffix = 6, 4, 2, 32, 40, 5
+        hq, hkv, d, prefix_len, suffix = 4, 2, 32, 40, 5
         q = torch.randn(b_total, hq, d).half()
         k_pre, v_pre = torch.randn(prefix_len, hkv, d).half(), torch.randn(prefix_len, hkv, d).half()
         k_uni = torch.randn(b_total, suffix, hkv, d).half()
@@ -53,8 +53,18 @@ def _worker(rank, world, port, ret):
             vm, sm = R.merge_state_ref(va.float(), sa, vb.float(), sb)
             return vm.half(), sm.float()
 
-        out = D.sharded_shared_prefix_decode(q[lo:hi], prefix_attend, unique_attend, merge_states_fn,
-                                             merge_state_fn)
+        sizes = [D.shard_range(b_total, world, r)[1] - D.shard_range(b_total, world, r)[0] for r in range(world)]
+        ex = D.SharedPrefixExchange(hq, d, torch.float16, "cpu", hi - lo, sizes)
+        for _ in range(2):  # the second step reuses every buffer
+            out = D.sharded_shared_prefix_decode(q[lo:hi], prefix_attend, unique_attend, merge_states_fn,
+                                                 merge_state_fn, batch_sizes=sizes, exchange=ex)
+        assert out.shape[0] == hi - lo
+        # one-shot form on the unpadded global batch
+        v_all, s_all = prefix_attend(q)
+        vx, sx = D.exchange_partial_states(v_all, s_all)
+        vm, _ = merge_states_fn(vx, sx)
+        full, _ = R.attention_ref(q[lo:hi].float(), k_pre.float(), v_pre.float())
+        assert (vm.float() - full.float()).abs().max().item() < 5e-3
         # reference: plain attention over [prefix | unique suffix] per request
         ref = torch.cat([
             R.attention_ref(q[i:i + 1].float(), torch.cat([k_pre, k_uni[i]]).float(),
@@ -70,12 +80,13 @@ def _worker(rank, world, port, ret):
 
 
 @pytest.mark.timeout(120)
-def test_sharded_shared_prefix_decode_world2():
+@pytest.mark.parametrize("b_total", [6, 7])  # 7: the ranks own 4 and 3 requests (padded collectives)
+def test_sharded_shared_prefix_decode_world2(b_total):
     world = 2
     port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
-        mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, ret, b_total), nprocs=world, join=True)
         assert len(ret) == world
         for r in range(world):
             assert ret[r] < 5e-3, ret[r]  # fp16 rounding of the exchanged states
