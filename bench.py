@@ -316,6 +316,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")  # single-rank FI_BENCH_FORCE_DIST run without a launcher
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         import datetime
 
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(minutes=10))

@@ -276,10 +276,17 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   FI_REQUIRE(kv.batch_size == plan_info[FI_PP_BATCH_SIZE], "batch_prefill_paged_run: batch size differs from the plan");
   FI_REQUIRE(kv.num_kv_heads > 0 && a->num_qo_heads % kv.num_kv_heads == 0,
              "batch_prefill_paged_run: num_qo_heads must be a multiple of num_kv_heads");
-  FI_REQUIRE(a->mask_mode >= FI_MASK_NON_CAUSAL && a->mask_mode <= FI_MASK_CUSTOM,
+  FI_REQUIRE(a->mask_mode >= FI_MASK_NON_CAUSAL && a->mask_mode <= FI_MASK_MULTIITEMSCORING,
              "batch_prefill_paged_run: bad mask_mode %d", a->mask_mode);
   FI_REQUIRE(a->mask_mode != FI_MASK_CUSTOM || (a->custom_mask && a->mask_indptr),
              "batch_prefill_paged_run: mask_mode CUSTOM needs custom_mask and mask_indptr");
+  FI_REQUIRE(a->mask_mode != FI_MASK_MULTIITEMSCORING ||
+                 (a->prefix_len_ptr && a->token_pos_in_items_ptr && a->token_pos_in_items_len > 0),
+             "batch_prefill_paged_run: mask_mode MULTIITEMSCORING needs prefix_len_ptr, token_pos_in_items_ptr and "
+             "token_pos_in_items_len");
+  FI_REQUIRE(a->mask_mode != FI_MASK_MULTIITEMSCORING ||
+                 (a->q_dtype == FI_DTYPE_F16 || a->q_dtype == FI_DTYPE_BF16),
+             "batch_prefill_paged_run: multi-item scoring needs 16-bit queries");
   if (check_prefill_dtypes("batch_prefill_paged_run", a->q_dtype, kv.dtype, a->o_dtype)) return 1;
   const int t16 = compute_type(a->q_dtype, a->o_dtype);
   prefill_launch_fn fn = find_prefill(t16, kv.dtype, a->q_dtype, kv.head_dim);
@@ -339,10 +346,17 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.page_size = kv.page_size;
   kp.page_div = FastDiv((uint32_t)kv.page_size);
   kp.group_div = FastDiv((uint32_t)kp.group_size);
-  kp.causal = a->mask_mode == FI_MASK_CAUSAL;
+  // multi-item scoring is causal plus the per-item predicate (ref: prefill.cuh:845-856); plan() must have
+  // been called with causal = true so that the kv range of a q tile ends at its last row
+  kp.causal = a->mask_mode == FI_MASK_CAUSAL || a->mask_mode == FI_MASK_MULTIITEMSCORING;
   if (a->mask_mode == FI_MASK_CUSTOM) {
     kp.custom_mask = a->custom_mask;
     kp.mask_indptr = a->mask_indptr;
+  }
+  if (a->mask_mode == FI_MASK_MULTIITEMSCORING) {
+    kp.prefix_len_ptr = a->prefix_len_ptr;
+    kp.token_pos_in_items_ptr = a->token_pos_in_items_ptr;
+    kp.token_pos_in_items_len = a->token_pos_in_items_len;
   }
   kp.window_left = a->window_left;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;

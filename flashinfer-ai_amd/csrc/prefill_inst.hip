@@ -25,7 +25,7 @@ static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
 }
 
 hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t stream) {
-  const bool general = p.use_alibi || p.logits_soft_cap > 0.f || p.custom_mask != nullptr;
+  const bool general = p.use_alibi || p.logits_soft_cap > 0.f || p.custom_mask != nullptr || p.prefix_len_ptr != nullptr;
   if (rope) return general ? launch<true, true>(p, stream) : launch<true, false>(p, stream);
   return general ? launch<false, true>(p, stream) : launch<false, false>(p, stream);
 }

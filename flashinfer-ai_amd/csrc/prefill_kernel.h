@@ -62,6 +62,11 @@ struct PrefillKernelParams {
   const float* scale_v;
   const uint8_t* custom_mask;    // packed bits (mask mode CUSTOM), NULL otherwise
   const int32_t* mask_indptr;    // per-request byte offsets into custom_mask (NULL: 0)
+  // multi-item scoring (mask mode MULTIITEMSCORING, ref: prefill.cuh:795-858): a query past the request's
+  // prefix sees the prefix and the tokens of its own item only
+  const uint32_t* prefix_len_ptr;          // [batch], NULL: off
+  const uint16_t* token_pos_in_items_ptr;  // [batch, token_pos_in_items_len]: position of a token in its item
+  int32_t token_pos_in_items_len;
   int64_t q_stride_n, q_stride_h;
   int64_t kv_stride_page, kv_stride_n, kv_stride_h;  // host checks stride_page / stride_n < 2^31
   int32_t num_work;
@@ -305,6 +310,18 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       (GENERAL && p.custom_mask) ? p.custom_mask + (p.mask_indptr ? p.mask_indptr[req] : 0) : nullptr;
   const uint64_t mask_row = (uint64_t)qo_idx * (uint64_t)kv_len;
   const uint64_t mask_bytes = ((uint64_t)qo_len * (uint64_t)kv_len + 7) >> 3;  // of this request
+  // multi-item scoring: this row's item starts at q_pos - item_pos (ref: logits_mask_multi_item_scoring,
+  // prefill.cuh:845-856: a query at p >= prefix_len sees kv_idx < prefix_len and kv_idx > p - token_pos[p - prefix])
+  int mi_prefix = 0x7fffffff, mi_item_lo = 0;  // rows inside the prefix: plain causal
+  if constexpr (GENERAL) {
+    if (p.prefix_len_ptr) {
+      const int pl = (int)p.prefix_len_ptr[req];
+      if (q_pos >= pl && q_pos < kv_len) {
+        mi_prefix = pl;
+        mi_item_lo = q_pos - (int)p.token_pos_in_items_ptr[(int64_t)req * p.token_pos_in_items_len + (q_pos - pl)];
+      }
+    }
+  }
 
   // ---- kv range of this workgroup ----
   int kv_end = kv_len;
@@ -594,6 +611,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
             if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg * inv_cap);
             lg *= inv_qk_scale;
             if (mask_bits) lg = ((mask_win[kbk] >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1) ? lg : -INFINITY;
+            if (p.prefix_len_ptr) lg = (kv_idx < mi_prefix || kv_idx > mi_item_lo) ? lg : -INFINITY;
             s_acc[kbk][r] = lg;
           }
       }

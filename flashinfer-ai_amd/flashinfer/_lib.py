@@ -116,6 +116,10 @@ class BatchPrefillParams(C.Structure):
         ("scale_v", C.c_void_p),
         ("custom_mask", C.c_void_p),
         ("mask_indptr", C.c_void_p),
+        ("prefix_len_ptr", C.c_void_p),
+        ("token_pos_in_items_ptr", C.c_void_p),
+        ("max_item_len_ptr", C.c_void_p),
+        ("token_pos_in_items_len", C.c_int32),
         ("num_qo_heads", C.c_int32),
         ("q_dtype", C.c_int32),
         ("o_dtype", C.c_int32),

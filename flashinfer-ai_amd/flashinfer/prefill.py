@@ -48,6 +48,36 @@ def _scale_tensor(x, n: int, device) -> Optional[torch.Tensor]:
     return x
 
 
+def _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len,
+                           batch_size, device):
+    """multi-item scoring operands (ref: flashinfer/prefill.py:1547-1558): uint32 prefix lengths, uint16 token
+    positions (row stride token_pos_in_items_len), uint16 max item lengths (optional here: only used by the
+    reference to skip masked tiles)."""
+    if prefix_len_ptr is None and token_pos_in_items_ptr is None and max_item_len_ptr is None:
+        return None, None, None, 0
+    if prefix_len_ptr is None or token_pos_in_items_ptr is None:
+        raise ValueError("multi-item scoring needs prefix_len_ptr and token_pos_in_items_ptr")
+    if prefix_len_ptr.dtype != torch.uint32 or token_pos_in_items_ptr.dtype != torch.uint16:
+        raise ValueError("prefix_len_ptr must be uint32 and token_pos_in_items_ptr uint16")
+    if max_item_len_ptr is not None and max_item_len_ptr.dtype != torch.uint16:
+        raise ValueError("max_item_len_ptr must be uint16")
+    if prefix_len_ptr.numel() != batch_size:
+        raise ValueError("prefix_len_ptr must have one entry per request")
+    if token_pos_in_items_len <= 0 or token_pos_in_items_ptr.numel() < (batch_size - 1) * token_pos_in_items_len + 1:
+        raise ValueError("token_pos_in_items_ptr is shorter than batch_size rows of token_pos_in_items_len")
+    return (prefix_len_ptr.to(device).contiguous(), token_pos_in_items_ptr.to(device).contiguous(),
+            None if max_item_len_ptr is None else max_item_len_ptr.to(device).contiguous(), int(token_pos_in_items_len))
+
+
+def _mask_mode(wrapper) -> int:
+    # ref: flashinfer/prefill.py:2091-2100
+    if wrapper._custom_mask_buf is not None:
+        return MaskMode.CUSTOM.value
+    if getattr(wrapper, "_prefix_len_ptr", None) is not None:
+        return MaskMode.MULTIITEMSCORING.value
+    return MaskMode.CAUSAL.value if wrapper._causal else MaskMode.NON_CAUSAL.value
+
+
 def _plan_custom_mask(wrapper, custom_mask, packed_custom_mask, qo_indptr_host, kv_lens_host, non_blocking):
     """(packed mask, byte indptr) on the wrapper's device, or (None, None).
     ref: _compute_page_mask_indptr + segment_packbits, flashinfer/prefill.py:1203-1223, 1693-1706; in
@@ -328,11 +358,15 @@ class BatchPrefillWithPagedKVCacheWrapper:
         custom_mask : flattened bool mask, request i contributes ``qo_len[i] * kv_len[i]`` entries
             (row-major ``[qo_len, kv_len]``); packed_custom_mask : its ``segment_packbits(..., "little")`` form.
             With a mask the mask mode is CUSTOM and ``causal`` is ignored (ref: prefill.py:1693-1706, 1890-1905).
-        Multi-item scoring is not implemented (ValueError).
+        prefix_len_ptr (uint32 ``[batch]``), token_pos_in_items_ptr (uint16 ``[batch * token_pos_in_items_len]``),
+        token_pos_in_items_len, max_item_len_ptr (uint16 ``[batch]``): multi-item scoring -- a query past the
+        request's prefix sees the prefix and the tokens of its own item (mask mode MULTIITEMSCORING; plan with
+        ``causal=True``; ref: prefill.py:1547-1558, 2099-2100, prefill.cuh:795-858).
         (ref: flashinfer/prefill.py:1523-1921)
         """
-        if prefix_len_ptr is not None or token_pos_in_items_ptr is not None or max_item_len_ptr is not None:
-            raise ValueError("multi-item scoring is not supported by the MI355X backend")
+        self._prefix_len_ptr, self._token_pos_in_items_ptr, self._max_item_len_ptr, self._token_pos_in_items_len = \
+            _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len,
+                                   len(qo_indptr) - 1, self.device)
         for tensor, name in [(qo_indptr, "qo_indptr"), (paged_kv_indptr, "paged_kv_indptr"),
                              (paged_kv_indices, "paged_kv_indices"),
                              (paged_kv_last_page_len, "paged_kv_last_page_len")]:
@@ -547,8 +581,9 @@ class BatchPrefillWithPagedKVCacheWrapper:
             scale_q=_lib.ptr(scale_q), scale_k=_lib.ptr(scale_k), scale_v=_lib.ptr(scale_v),
             num_qo_heads=self._num_qo_heads, q_dtype=_lib.fi_dtype(q.dtype), o_dtype=_lib.fi_dtype(o_dtype),
             custom_mask=_lib.ptr(self._custom_mask_buf), mask_indptr=_lib.ptr(self._mask_indptr_buf),
-            mask_mode=(MaskMode.CUSTOM.value if self._custom_mask_buf is not None
-                       else MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value),
+            prefix_len_ptr=_lib.ptr(self._prefix_len_ptr), token_pos_in_items_ptr=_lib.ptr(self._token_pos_in_items_ptr),
+            max_item_len_ptr=_lib.ptr(self._max_item_len_ptr), token_pos_in_items_len=self._token_pos_in_items_len,
+            mask_mode=_mask_mode(self),
             pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=window_left,
             logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
             rope_rcp_theta=1.0 / rope_theta,
@@ -682,8 +717,9 @@ class BatchPrefillWithRaggedKVCacheWrapper:
     ) -> None:
         r"""Plan for ragged queries ``qo_indptr`` and ragged keys/values ``kv_indptr`` (both int32
         ``[batch_size + 1]``).  Options as :meth:`BatchPrefillWithPagedKVCacheWrapper.plan`."""
-        if prefix_len_ptr is not None or token_pos_in_items_ptr is not None or max_item_len_ptr is not None:
-            raise ValueError("multi-item scoring is not supported by the MI355X backend")
+        self._prefix_len_ptr, self._token_pos_in_items_ptr, self._max_item_len_ptr, self._token_pos_in_items_len = \
+            _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len,
+                                   len(qo_indptr) - 1, self.device)
         for tensor, name in [(qo_indptr, "qo_indptr"), (kv_indptr, "kv_indptr")]:
             if tensor.dtype != torch.int32:
                 raise ValueError(f"{name} must have dtype torch.int32, got {tensor.dtype}")
@@ -817,9 +853,10 @@ class BatchPrefillWithRaggedKVCacheWrapper:
             o=out.data_ptr(), lse=_lib.ptr(lse) if return_lse else None, alibi_slopes=_lib.ptr(alibi),
             scale_q=None, scale_k=None, scale_v=None, num_qo_heads=self._num_qo_heads,
             custom_mask=_lib.ptr(self._custom_mask_buf), mask_indptr=_lib.ptr(self._mask_indptr_buf),
+            prefix_len_ptr=_lib.ptr(self._prefix_len_ptr), token_pos_in_items_ptr=_lib.ptr(self._token_pos_in_items_ptr),
+            max_item_len_ptr=_lib.ptr(self._max_item_len_ptr), token_pos_in_items_len=self._token_pos_in_items_len,
             q_dtype=_lib.fi_dtype(q.dtype), o_dtype=_lib.fi_dtype(q.dtype),
-            mask_mode=(MaskMode.CUSTOM.value if self._custom_mask_buf is not None
-                       else MaskMode.CAUSAL.value if self._causal else MaskMode.NON_CAUSAL.value),
+            mask_mode=_mask_mode(self),
             pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=self._window_left,
             logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
             rope_rcp_theta=1.0 / rope_theta,

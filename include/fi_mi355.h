@@ -51,7 +51,7 @@ enum fi_dtype {
 
 /* ref: flashinfer/utils.py:30-46 */
 enum fi_pos_encoding_mode { FI_POS_NONE = 0, FI_POS_ROPE_LLAMA = 1, FI_POS_ALIBI = 2 };
-enum fi_mask_mode { FI_MASK_NON_CAUSAL = 0, FI_MASK_CAUSAL = 1, FI_MASK_CUSTOM = 2 };
+enum fi_mask_mode { FI_MASK_NON_CAUSAL = 0, FI_MASK_CAUSAL = 1, FI_MASK_CUSTOM = 2, FI_MASK_MULTIITEMSCORING = 3 };
 
 /* ------------------------------------------------------------------------------------------------
  * library / device information
@@ -256,10 +256,19 @@ typedef struct fi_batch_prefill_params {
    * layout, ref prefill.py:1203-1223, 1693-1706) */
   const uint8_t* custom_mask;
   const int32_t* mask_indptr; /* [batch+1] device, byte offsets */
+  /* mask_mode MULTIITEMSCORING (ref: maybe_prefix_len_ptr / maybe_token_pos_in_items_ptr / maybe_max_item_len_ptr /
+   * token_pos_in_items_len of paged_run, csrc/batch_prefill.cu:199-205, include/flashinfer/attention/prefill.cuh
+   * :795-858): causal, and a query at position p >= prefix_len[b] sees only the prefix and the keys
+   * kv_idx > p - token_pos_in_items[b][p - prefix_len[b]] (its own item).  max_item_len is accepted for
+   * signature parity (the reference uses it to skip fully masked tiles) and may be NULL. */
+  const uint32_t* prefix_len_ptr;         /* [batch] device */
+  const uint16_t* token_pos_in_items_ptr; /* [batch, token_pos_in_items_len] device */
+  const uint16_t* max_item_len_ptr;       /* [batch] device, optional */
+  int32_t token_pos_in_items_len;
   int32_t num_qo_heads;
   int32_t q_dtype; /* f16 / bf16 / fp8_e4m3 (then kv must be fp8_e4m3 too) */
   int32_t o_dtype; /* f16 / bf16 */
-  int32_t mask_mode; /* fi_mask_mode: NON_CAUSAL / CAUSAL / CUSTOM */
+  int32_t mask_mode; /* fi_mask_mode: NON_CAUSAL / CAUSAL / CUSTOM / MULTIITEMSCORING */
   int32_t pos_encoding_mode;
   int32_t window_left;
   float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;

@@ -27,7 +27,8 @@ def gem():
 
 
 def t(a):
-    return torch.from_numpy(np.asarray(a))
+    # C order: a transposed tensor is stored Fortran-ordered by numpy and would come back non-contiguous
+    return torch.from_numpy(np.ascontiguousarray(a))
 
 
 def paged_from_dense(k, v, page_size, seed):
