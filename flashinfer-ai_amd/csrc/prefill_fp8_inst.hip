@@ -1,16 +1,33 @@
 // fp8-native prefill (prefill_fp8_kernel.h): launchers for the two output types.
+// FI_PREFILL_FP8_V1=1 selects the first structure (prefill_fp8_v1_kernel.h) for A/B runs.
+#include <stdlib.h>
+
 #include "prefill_fp8_kernel.h"
 
 namespace fi {
 
+template <int OUT16>
+static hipError_t launch_v2(const PrefillKernelParams& p, int grid, hipStream_t stream) {
+  batch_prefill_fp8_kernel<OUT16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+  return hipGetLastError();
+}
+
 hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, hipStream_t stream) {
   const int grid = p.num_work * p.num_kv_heads;
   if (grid == 0) return hipSuccess;
-  if (out_dtype == FI_DTYPE_BF16)
-    batch_prefill_fp8_kernel<FI_DTYPE_BF16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-  else
-    batch_prefill_fp8_kernel<FI_DTYPE_F16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-  return hipGetLastError();
+  static const bool v1 = [] {
+    const char* e = getenv("FI_PREFILL_FP8_V1");
+    return e && atoi(e) != 0;
+  }();
+  if (v1) {
+    if (out_dtype == FI_DTYPE_BF16)
+      batch_prefill_fp8_v1_kernel<FI_DTYPE_BF16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    else
+      batch_prefill_fp8_v1_kernel<FI_DTYPE_F16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    return hipGetLastError();
+  }
+  return out_dtype == FI_DTYPE_BF16 ? launch_v2<FI_DTYPE_BF16>(p, grid, stream)
+                                    : launch_v2<FI_DTYPE_F16>(p, grid, stream);
 }
 
 }  // namespace fi

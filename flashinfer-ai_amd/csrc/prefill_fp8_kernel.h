@@ -1,60 +1,73 @@
-// fp8-native batch paged prefill for gfx950 (BASELINE config C3): Q, K, V are e4m3 and BOTH contractions
-// run on the block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 with unit (E8M0 = 127) block scales,
-// i.e. the plain fp8 product at twice the rate of the 16-bit / non-scaled fp8 MFMA.
+// fp8-native batch paged prefill for gfx950 (BASELINE config C3), second structure.
 //
-// Same decomposition as prefill_kernel.h (workgroup = 4 waves = 128 GQA-packed query rows x one kv head,
-// 64-row kv tiles, S^T = K Q^T with the query row on the lane, O^T += V^T P^T with the S^T accumulator
-// registers as the B operand).  Differences:
-//   * K=64 per MFMA: S^T needs 2 MFMAs per 32-row kv block (head_dim 128), O^T needs ONE MFMA per 32-row
-//     block of head_dim per 64-row kv tile: 8 MFMAs (512 pipe cycles) per tile and wave instead of 32 (1024).
-//   * P is quantised to e4m3 (x448) in registers exactly as the reference does
-//     (hopper/variants.cuh:72, 84-90) and used directly as the B operand: lane (q, h) holds the 32
-//     probabilities kv = 32 kb + 8 g + 4 h + e  (kb<2, g<4, e<4) in accumulator order.
-//   * V has to be the A operand with that same k order along each head_dim row.  The V tile stays
-//     ROW-MAJOR in LDS ([64 kv][128 B], staged exactly like K with 16-byte loads and ds_write_b128) and is
-//     transposed on the way out by ds_read_b64_tr_b8: in a 16-lane group, lanes 2b and 2b+1 address the
-//     16 bytes of "row b" (any row), and lane j receives byte j of rows 0..7 -- so each lane gathers, per
-//     read, the 8 kv rows of its k order for its own head_dim column.
-//   * both images are XOR-swizzled on 16-byte chunks so that every LDS access is conflict-free.
-//   * page gather: one wave per tile resolves (page id, entry) of the 64 kv rows into a byte-offset table
-//     in LDS, two tiles ahead; K and V share it.
-// Softmax arithmetic (ref hopper/attention_updater.cuh:167-256): row sum from the UNROUNDED probabilities,
-// O *= scale_v / 448 / rowsum at the end, lse = m + log2(sum) in base 2.
+// Arithmetic (unchanged; ref FA3 fp8: hopper/variants.cuh:64-102, attention_updater.cuh:167-256,
+// quantization/mainloop_mma.cuh:21-237): Q, K, V e4m3; S = Q K^T and O = P8 V on
+// v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales; P = 2^(c S - m), row sum from the UNROUNDED P,
+// P8 = e4m3(P x const) in registers as the B operand of the second product; O *= scale_v / rowsum at the end;
+// lse = m + log2(rowsum) in base 2.
+//
+// Decomposition (as prefill_kernel.h): workgroup = 4 waves = 128 GQA-packed query rows x one kv head, two
+// workgroups per CU (2 waves per SIMD: the softmax is vector-issue bound, and a SIMD issues vector
+// instructions from two waves at twice the rate of one); 64-key tiles; S^T = K Q^T with the query row on the
+// lane; O^T += V^T P^T with the S^T accumulator registers (as e4m3) as the B operand.
+//
+// What changed against the first structure (prefill_fp8_v1_kernel.h, 29 % of the MFMA peak, 25 vector
+// instructions per MFMA, matrix pipe idle two thirds of the time):
+//   * K / V tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) three
+//     tiles ahead through a ring of four 16 KB stages: no staging registers, no ds_write, no vector load in
+//     the loop at all (hand-counted vmcnt + raw s_barrier; every LDS object lives in ONE array).  Both images
+//     keep their XOR swizzles: the DMA destination is lane-linear, so the swizzle is applied to the per-lane
+//     SOURCE chunk.  Page ids sit in LDS (1024 at a time), one wave per tile turns (page id, entry) of the 64
+//     rows into byte offsets -- the steady state issues no ordinary global load.
+//   * software pipeline inside a wave: iteration t issues the four QK^T MFMAs of tile t+1 interleaved with
+//     the exp2 / sum / e4m3 packing of tile t, then the four P.V MFMAs of tile t interleaved with the row
+//     maximum of tile t+1.  A wave issues in order, so vector work has to sit BETWEEN its MFMAs in program
+//     order to run under them.
+//   * deferred rescale: the reference exponent m only moves when a row of the wave outgrows it by more than
+//     2^kF8Thr; P8 = e4m3(P x 448 / 2^kF8Thr) keeps the e4m3 range (P <= 2^kF8Thr).  The rescale of the 64
+//     O registers leaves the common path.
+//   * the loop body exists for each ring stage (all LDS addresses are a lane constant plus an immediate) and
+//     without / with the mask code (tiles on the causal diagonal or past kv_len run the masked body).
+//   * output rows leave through LDS: 16-byte stores of whole 256-byte rows instead of 8-byte pieces.
 #pragma once
 #include <type_traits>
 
-#include "prefill_kernel.h"
+#include "prefill_fp8_v1_kernel.h"
 
-#ifndef FI_PF8_KO
-#define FI_PF8_KO 0  // experiments only, bit mask: 1 no K/V loads and LDS stores in the tile loop, 2 no exp2 in the softmax
-#endif
 namespace fi {
 
-using i32x8 = __attribute__((ext_vector_type(8))) int;
-using i32x2 = __attribute__((ext_vector_type(2))) int;
+constexpr int kF8Stages = 4;        // ring depth (K and V each): tile t+1 / t read, t+2 landed, t+3 in flight
+constexpr int kF8KTile = kTileKV * 128;
+constexpr int kF8VOff = kF8Stages * kF8KTile;            // V ring after the K ring
+constexpr int kF8TabOff = 2 * kF8Stages * kF8KTile;      // uint64 [4][64] row byte offsets
+constexpr int kF8Ids = 1024;                             // page ids held in LDS
+constexpr int kF8IdsOff = kF8TabOff + 4 * kTileKV * 8;
+constexpr int kF8Smem = kF8IdsOff + kF8Ids * 4;          // 71 680 B: two workgroups per CU
+constexpr float kF8Thr = 3.0f;                           // log2 headroom of the deferred rescale
+constexpr float kF8Log2Scale = 8.807354922057604f - kF8Thr;  // log2(448) - headroom
 
-__device__ __forceinline__ f32x16 mfma_fp8_k64(i32x8 a, i32x8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, /*A fmt e4m3*/ 0, /*B fmt e4m3*/ 0, 0,
-                                                         0x7F7F7F7F, 0, 0x7F7F7F7F);
+// transposed 8-bit LDS read, issued from an asm statement: as an intrinsic the compiler cannot tell it from the
+// LDS-DMA targets and drains vmcnt in front of it.  Its completion is awaited by hand (counted lgkmcnt; LDS
+// operations of a wave return in order, and the compiler's own counted waits only get stricter).
+template <int OFF>
+__device__ __forceinline__ i32x2 lds_tr8(int addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  i32x2 w;
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(w) : "v"(addr), "i"(OFF));
+  return w;
 }
 
-// OUT16: output dtype (FI_DTYPE_F16 / FI_DTYPE_BF16); head_dim 128; page_size % 4 == 0
-#ifndef FI_FP8_WAVES_PER_SIMD
-#define FI_FP8_WAVES_PER_SIMD 2
-#endif
-template <int OUT16>
-__global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
-    batch_prefill_fp8_kernel(const PrefillKernelParams p) {
-  constexpr int D = 128;
-  constexpr int K_ROWB = 128;               // bytes per row of the K image (one kv row)
-  constexpr int V_ROWB = 128;               // bytes per row of the V image (one kv row)
-  constexpr int K_TILE = kTileKV * K_ROWB;  // 8 KB
-  constexpr int V_TILE = kTileKV * V_ROWB;  // 8 KB
-  constexpr int STAGE = K_TILE + V_TILE;
-  constexpr int DBLK = D / 32;
+typedef __attribute__((address_space(3))) void f8_lds_void;
+typedef const __attribute__((address_space(1))) void f8_gbl_void;
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
-  __shared__ uint64_t row_off_tab[4][kTileKV];  // byte offset of every kv row of a tile; slot = tile % 4
+template <int OUT16>
+__global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
+  constexpr int D = 128;
+  constexpr int DBLK = D / 32;
+  // ONE static array for every LDS object: the compiler separates an LDS-DMA target from an LDS read by
+  // constant offsets (and index ranges) inside one object; with a second object, or unbounded indices, it
+  // puts s_waitcnt vmcnt(0) in front of the reads and the prefetch is gone
+  __shared__ __attribute__((aligned(1024))) char smem[kF8Smem];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -74,7 +87,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   const int kv_head = logical / p.num_work;
   const int work = logical - kv_head * p.num_work;
   int req = 0, q_tile = work, kv_chunk = 0;
-  const bool split = p.kv_tile_indices != nullptr || p.num_kv_chunks > 1;  // see prefill_kernel.h
+  const bool split = p.kv_tile_indices != nullptr || p.num_kv_chunks > 1;
   if (p.request_indices) {
     req = p.request_indices[work];
     q_tile = p.qo_tile_indices[work];
@@ -84,7 +97,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     q_tile = work / p.num_kv_chunks;
     kv_chunk = work - q_tile * p.num_kv_chunks;
   }
-  int qo_start = 0, qo_len, kv_len, page_begin = 0;
+  int qo_start = 0, qo_len, kv_len, page_begin = 0, num_pages = 0;
   if (p.qo_indptr) {
     qo_start = p.qo_indptr[req];
     qo_len = p.qo_indptr[req + 1] - qo_start;
@@ -93,12 +106,12 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   }
   if (p.kv_indptr) {
     page_begin = p.kv_indptr[req];
-    const int np = p.kv_indptr[req + 1] - page_begin;
-    // ragged KV (no last_page_len): every page is full (ref ragged wrapper: prefill.py:2255-3007)
-    kv_len = p.kv_last_page_len ? (np > 0 ? (np - 1) * p.page_size + p.kv_last_page_len[req] : 0)
-                                : np * p.page_size;
+    num_pages = p.kv_indptr[req + 1] - page_begin;
+    kv_len = p.kv_last_page_len ? (num_pages > 0 ? (num_pages - 1) * p.page_size + p.kv_last_page_len[req] : 0)
+                                : num_pages * p.page_size;
   } else {
     kv_len = p.single_kv_len;
+    num_pages = (kv_len + p.page_size - 1) / p.page_size;
   }
   const int G = p.group_size;
   const int packed_len = qo_len * G;
@@ -111,7 +124,7 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
   const int qo_head = kv_head * G + hg;
   const int q_pos = kv_len - qo_len + qo_idx;
 
-  // ---- Q fragments: lane (q, h) holds bytes [64 kk + 32 h, +32) of its row ----
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (q, h) holds bytes [64 kk + 32 h, +32) of its row ----
   i32x8 qf[2];
   {
     const uint8_t* qrow = (const uint8_t*)p.q + (int64_t)(qo_start + qo_idx) * p.q_stride_n +
@@ -136,244 +149,365 @@ __global__ void __launch_bounds__(kPrefillThreads, FI_FP8_WAVES_PER_SIMD)
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
   int kv_begin = 0;
-  if (split) {  // split-KV work item (see prefill_kernel.h)
+  if (split) {
     const int kv_chunk_size = p.kv_chunk_size_ptr ? *p.kv_chunk_size_ptr : p.kv_chunk_size;
     kv_begin = kv_chunk * kv_chunk_size;
     kv_end = min(kv_end, kv_begin + kv_chunk_size);
   }
   const int tile_base = kv_begin / kTileKV;
   const int num_tiles = kv_end > kv_begin ? (kv_end - kv_begin + kTileKV - 1) / kTileKV : 0;
-  // a row that sees no key (causal with qo_len > kv_len) gets a range no index can fall into
   const int vis_hi_raw = p.causal ? min(kv_len - 1, q_pos) : kv_len - 1;
   const int vis_lo = vis_hi_raw < 0 ? 0x40000000 : 0;
   const int vis_hi = vis_hi_raw < 0 ? 0x40000000 : vis_hi_raw;
   const int first_qo_wave = (int)fast_div((uint32_t)min(row0, max(packed_len - 1, 0)), p.group_div);
   const int min_qpos_wave = kv_len - qo_len + first_qo_wave;
+  // a tile needs the mask code when it reaches past kv_len or past the smallest query position of the wave
+  auto tile_needs_mask = [&](int t) {
+    const int tile0 = (tile_base + t) * kTileKV;
+    return (tile0 + kTileKV > kv_len) || (p.causal && tile0 + kTileKV - 1 > min_qpos_wave);
+  };
 
-  // ---- staging geometry: K and V alike, thread -> (row = tid/8 + 32 pass, 16-byte chunk tid%8) ----
-  const int k_row = tid >> 3, k_ch = tid & 7;
+  // ---- lane constants of the LDS images (same swizzles as the first structure) ----
+  // DMA: thread -> (row = tid / 8 [+ 32], 16-byte slot tid % 8); the slot receives global chunk slot ^ swizzle(row)
+  const int st_row = tid >> 3, st_slot = tid & 7;
+  const int kc = (st_slot ^ ((st_row >> 1) & 7)) << 4;
+  const int vc = (st_slot ^ ((((st_row >> 1) & 1) << 1) | (((st_row >> 3) & 1) << 2))) << 4;
   const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
-  const char* const k_thr = (const char*)p.k + head_off + k_ch * 16;
-  const char* const v_thr = (const char*)p.v + head_off + k_ch * 16;
+  const char* const k_thr = (const char*)p.k + head_off + kc;
+  const char* const v_thr = (const char*)p.v + head_off + vc;
   const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
-  auto tab_lookup = [&](int tile, int& pg, int& en) {
-    const int kvi = max(min(tile * kTileKV + lane, kv_len - 1), 0);
-    const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
-    en = kvi - pi * p.page_size;
-    pg = p.kv_indices ? p.kv_indices[page_begin + pi] : page_begin + pi;
-  };
-  auto tab_store = [&](int slot, int pg, int en) {
-    row_off_tab[slot][lane] = (uint64_t)(uint32_t)pg * stride_page32 + (uint64_t)(uint32_t)en * stride_n32;
-  };
-  struct Stage {
-    u32x4 k[2], v[2];
-  };
-  auto issue_loads = [&](int slot, Stage& st) {
+  // K fragment (A operand): row lq (+32 kb), chunks 4 kk + 2 lh + e, chunk ^ ((row >> 1) & 7)
+  int k_rd[2][2];
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const uint64_t off = row_off_tab[slot][k_row + 32 * ps];
-      st.k[ps] = *(const u32x4*)(k_thr + off);
-      st.v[ps] = *(const u32x4*)(v_thr + off);
-    }
-  };
-  auto k_lds_off = [](int row, int ch) { return row * K_ROWB + ((ch ^ ((row >> 1) & 7)) << 4); };
-  // V chunk swizzle: the 8 rows of one transposed read are r0 + {0..3, 8..11}; bits 1 and 3 of the row
-  // tell the four rows of either parity apart
-  auto v_swz = [](int row) { return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2); };
-  auto write_stage = [&](int buf, const Stage& st) {
-    char* kb = smem + buf * STAGE;
-    char* vb = kb + K_TILE;
+  for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int row = k_row + 32 * ps;
-      *(u32x4*)(kb + k_lds_off(row, k_ch)) = st.k[ps];
-      *(u32x4*)(vb + row * V_ROWB + ((k_ch ^ v_swz(row)) << 4)) = st.v[ps];
-    }
-  };
-
-  // ---- per-lane LDS read offsets ----
-  // K fragment: row lq (+32 kb), 16-byte chunks 4 kk + 2 lh + e.  The three chunk bits are disjoint
-  // (bit 0: e, bit 1: lh, bit 2: kk), so every address is ONE lane-constant base XOR a literal -- one
-  // register instead of four (the kernel sits at the 256-register line; see the spill note below)
-  int k_rd_base = k_lds_off(lq, 2 * lh);
-  auto k_rd = [&](int kk, int e) { return k_rd_base ^ ((4 * kk + e) << 4); };
-  // V^T fragment (A operand): lane (d = 32 db + 16 g + j, lh) needs, as byte p = 8 r + b of its 32 bytes,
-  // V[kv(p)][d] with kv(p) = 32 (p >> 4) + 8 ((p & 15) >> 2) + 4 lh + (p & 3) -- the order in which the
-  // S^T accumulator registers hold P.  Transposed read r covers p = 8 r .. 8 r + 7: rows
-  // 32 (r >> 1) + 16 (r & 1) + 4 lh + {0..3, 8..11}; lane i of the 16-lane group addresses row b = i >> 1,
-  // bytes 8 (i & 1) .. +8 of chunk 2 db + g.
-  int v_rd_base;  // chunk 2 db + g: db occupies chunk bits 1-2, so v_rd(db) = base ^ (db << 5)
+    for (int e = 0; e < 2; ++e) k_rd[kk][e] = lq * 128 + (((4 * kk + 2 * lh + e) ^ ((lq >> 1) & 7)) << 4);
+  // V^T fragment: see prefill_fp8_v1_kernel.h (transposed 8-bit read; lane i of a 16-lane group addresses row
+  // b = i >> 1, bytes 8 (i & 1) .. +8 of chunk 2 db + g)
+  int v_rd[DBLK];
   {
     const int i16 = lane & 15, g = (lane >> 4) & 1, b = i16 >> 1;
     const int row = 4 * lh + (b & 3) + 8 * (b >> 2);
-    v_rd_base = row * V_ROWB + ((g ^ v_swz(row)) << 4) + 8 * (i16 & 1);
+    const int sw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+    const int base = row * 128 + ((g ^ sw) << 4) + 8 * (i16 & 1);
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db) v_rd[db] = base ^ (db << 5);  // ring / stage / row-block offsets: immediates
   }
-  auto v_rd = [&](int db) { return v_rd_base ^ (db << 5); };
+  uint64_t* const tab = (uint64_t*)(smem + kF8TabOff);
+  int32_t* const ids = (int32_t*)(smem + kF8IdsOff);
 
+  // ---- running state ----
   f32x16 o_acc[DBLK];
 #pragma unroll
   for (int db = 0; db < DBLK; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
+  float m_adj = m_run - kF8Log2Scale;  // exp2 argument offset: P x 448 / 2^kF8Thr = 2^(c s - m_adj)
 
   if (num_tiles > 0) {
-    Stage st;
-    if (wave < 2) {
-      int pg0, en0;
-      tab_lookup(tile_base + min(wave, num_tiles - 1), pg0, en0);
-      tab_store(wave, pg0, en0);
-    }
-    __syncthreads();
-    issue_loads(0, st);
-    write_stage(0, st);
-    __syncthreads();
-    // The next tile is always staged (past the end: the last tile again, into the idle buffer), so there
-    // is no branch around a load.  The row-offset table of tile t+2 is produced during tile t by wave t % 4.
-    auto tile_body = [&](auto buf_c, const int t) {
-      constexpr int buf = decltype(buf_c)::value;
-      // keep the derived LDS addresses out of the loop-invariant set: hoisted, they cost four registers
-      // each, get spilled, and every reload (a VMEM op) drags a vmcnt(0) wait -- on the K/V loads just
-      // issued -- into the MFMA section
-      asm volatile("" : "+v"(k_rd_base), "+v"(v_rd_base));
-      if (!(FI_PF8_KO & 1)) issue_loads((t + 1) & 3, st);
-      const bool tab_wave = wave == (t & 3);
-      int tab_pg = 0, tab_en = 0;
-      if (tab_wave) tab_lookup(tile_base + min(t + 2, num_tiles - 1), tab_pg, tab_en);
-      const char* kb = smem + buf * STAGE;
-      const char* vb = kb + K_TILE;
-      const int tile0 = (tile_base + t) * kTileKV;
-
-      // ---- S^T = K Q^T: 2 kv blocks x 2 k-steps of 64 ----
-      f32x16 s_acc[2];
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const u32x4 lo = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd(kk, 0));
-          const u32x4 hi = *(const u32x4*)(kb + kbk * 32 * K_ROWB + k_rd(kk, 1));
-          const i32x8 a = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-          s_acc[kbk] = mfma_fp8_k64(a, qf[kk], s_acc[kbk]);
+    // ---- page ids of this kv range -> LDS (refilled when the walk leaves the window) ----
+    int ids_base = (int)fast_div((uint32_t)min(tile_base * kTileKV, max(kv_len - 1, 0)), p.page_div);
+    auto fill_ids = [&]() {
+      if (p.kv_indices) {
+        for (int i = tid; i < kF8Ids; i += kPrefillThreads) {
+          const int pg = ids_base + i;
+          ids[i] = pg < num_pages ? p.kv_indices[page_begin + pg] : 0;
         }
       }
+    };
+    // byte offsets of the 64 rows of tile `t_rel` (clamped to the last tile): one row per lane
+    auto make_tab = [&](int t_rel, int slot) {
+      const int tile = tile_base + min(t_rel, num_tiles - 1);
+      const int kvi = max(min(tile * kTileKV + lane, kv_len - 1), 0);
+      const int pi = (int)fast_div((uint32_t)kvi, p.page_div);
+      const int en = kvi - pi * p.page_size;
+      const int pg = p.kv_indices ? ids[(pi - ids_base) & (kF8Ids - 1)] : page_begin + pi;  // index range visible
+      tab[slot * kTileKV + lane] = (uint64_t)(uint32_t)pg * stride_page32 + (uint64_t)(uint32_t)en * stride_n32;
+    };
+    // page window check for the tile whose table is made next (uniform)
+    auto ids_cover = [&](int t_rel) {
+      const int tile = tile_base + min(t_rel, num_tiles - 1);
+      const int k0 = max(min(tile * kTileKV, kv_len - 1), 0), k1 = max(min(tile * kTileKV + kTileKV - 1, kv_len - 1), 0);
+      const int p0 = (int)fast_div((uint32_t)k0, p.page_div), p1 = (int)fast_div((uint32_t)k1, p.page_div);
+      return p0 >= ids_base && p1 - ids_base < kF8Ids;
+    };
+    // DMA of tile t_rel's K and V rows into ring stage `stage` (row offsets from table slot `slot`)
+    auto dma_tile = [&](int slot, int stage) {
+      const uint64_t off0 = tab[slot * kTileKV + st_row];
+      const uint64_t off1 = tab[slot * kTileKV + st_row + 32];
+      char* const kdst = smem + stage * kF8KTile + wave * 1024;
+      char* const vdst = kdst + kF8VOff;
+      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off0), (f8_lds_void*)(kdst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off1), (f8_lds_void*)(kdst + 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off0), (f8_lds_void*)(vdst), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off1), (f8_lds_void*)(vdst + 4096), 16, 0, 0);
+    };
 
-      const bool need_mask = (tile0 + kTileKV > kv_len) || (p.causal && tile0 + kTileKV - 1 > min_qpos_wave);
-      if (need_mask) {
-        const unsigned span = (unsigned)(vis_hi - vis_lo);
-        const int base_idx = tile0 + 4 * lh - vis_lo;
-#pragma unroll
-        for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const unsigned rel = (unsigned)(base_idx + 32 * kbk + (r & 3) + 8 * (r >> 2));
-            s_acc[kbk][r] = rel <= span ? s_acc[kbk][r] : -INFINITY;
-          }
-      }
+    fill_ids();
+    __syncthreads();
+    make_tab(wave, wave);  // tables of tiles 0..3 (clamped)
+    __syncthreads();
+    dma_tile(0, 0);
+    dma_tile(1, 1);
+    dma_tile(2, 2);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tiles 0 and 1 have landed (tile 2: 4 pieces in flight)
+    __builtin_amdgcn_s_barrier();
 
-      // ---- online softmax (base 2) ----
-      float mx = s_acc[0][0];
-#pragma unroll
-      for (int kbk = 0; kbk < 2; ++kbk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s_acc[kbk][r]);
-      mx = fmaxf(mx, swap_halves(mx));
-      const float m_new = fmaxf(m_run, mx * c_log2);
-      const float alpha = fast_exp2(m_run - m_new);
-      m_run = m_new;
-      // p * 448 = 2^(s c - m + log2 448): the e4m3 scale is folded into the exponent; the row sum is taken
-      // from these unrounded values and divided by 448 once at the end
-      const float m_adj = m_new - 8.807354922057604f;  // log2(448)
-      float psum = 0.f;
+    // ---- building blocks ----
+    const i32x8 q0 = qf[0], q1 = qf[1];
+    auto k_frag = [&](const char* kb, int i) {  // fragment i = 2 kbk + kk of the K tile at kb
+      const u32x4 lo = *(const u32x4*)(kb + (i >> 1) * 4096 + k_rd[i & 1][0]);
+      const u32x4 hi = *(const u32x4*)(kb + (i >> 1) * 4096 + k_rd[i & 1][1]);
+      return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
+    auto apply_mask = [&](int t_rel, f32x16 (&s)[2]) {
+      const int tile0 = (tile_base + t_rel) * kTileKV;
+      const unsigned span = (unsigned)(vis_hi - vis_lo);
+      const int base_idx = tile0 + 4 * lh - vis_lo;
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s_acc[kbk][r] = (FI_PF8_KO & 2) ? __builtin_fmaf(s_acc[kbk][r], c_log2, -m_adj)
-                                          : fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_adj));
-          psum += s_acc[kbk][r];
+          const unsigned rel = (unsigned)(base_idx + 32 * kbk + (r & 3) + 8 * (r >> 2));
+          s[kbk][r] = rel <= span ? s[kbk][r] : -INFINITY;
         }
-      l_run = l_run * alpha + psum;
-      if (__any(alpha != 1.0f)) {
+    };
+    // running maximum over registers r0 .. r0 + 7 of a score block
+    auto max_chunk = [&](const f32x16& s, int r0, float mx) {
+      mx = fmaxf(fmaxf(mx, s[r0]), s[r0 + 1]);
+      mx = fmaxf(fmaxf(mx, s[r0 + 2]), s[r0 + 3]);
+      mx = fmaxf(fmaxf(mx, s[r0 + 4]), s[r0 + 5]);
+      return fmaxf(fmaxf(mx, s[r0 + 6]), s[r0 + 7]);
+    };
+    // moves the reference exponent only when a row outgrew it by more than 2^kF8Thr (rare path)
+    auto rescale_if_needed = [&](float mx, const bool real_tile) {
+      mx = fmaxf(mx, swap_halves(mx));
+      // scores of a tile past the end (the pipeline runs one tile ahead) must not move the exponent
+      const float m_true = real_tile ? fmaxf(m_run, mx * c_log2) : m_run;  // c_log2 > 0
+      if (__any(m_true - m_run > kF8Thr)) {
+        const float alpha = fast_exp2(m_run - m_true);
+        m_run = m_true;
+        m_adj = m_true - kF8Log2Scale;
+        l_run *= alpha;
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
           for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
       }
-
-      // ---- P -> e4m3, the B operand (32 bytes per lane, accumulator order) ----
-      i32x8 p8;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int kbk = j >> 2, r = 4 * (j & 3);
-        int w = __builtin_amdgcn_cvt_pk_fp8_f32(s_acc[kbk][r], s_acc[kbk][r + 1], 0, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(s_acc[kbk][r + 2], s_acc[kbk][r + 3], w, true);
-        p8[j] = w;
-      }
-
-      // ---- O^T += V^T P^T: one K=64 MFMA per 32 rows of head_dim, A gathered by 4 transposed reads ----
-#pragma unroll
-      for (int db = 0; db < DBLK; ++db) {
-        i32x8 a;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const i32x2 w = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-              (__attribute__((address_space(3))) i32x2*)(vb + (32 * (r >> 1) + 16 * (r & 1)) * V_ROWB + v_rd(db)));
-          a[2 * r] = w[0];
-          a[2 * r + 1] = w[1];
-        }
-        o_acc[db] = mfma_fp8_k64(a, p8, o_acc[db]);
-      }
-
-      if (!(FI_PF8_KO & 1)) write_stage(buf ^ 1, st);
-      if (tab_wave) tab_store((t + 2) & 3, tab_pg, tab_en);
-      __syncthreads();
     };
-    int t = 0;
-    for (; t + 1 < num_tiles; t += 2) {
-      tile_body(std::integral_constant<int, 0>{}, t);
-      tile_body(std::integral_constant<int, 1>{}, t + 1);
+    // exp2 of registers r0 .. r0 + 7 of a score block: their sum and their e4m3 image (two words of the B operand)
+    auto exp_chunk = [&](const f32x16& s, int r0, int& w0, int& w1, float& ps) {
+      float x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = fast_exp2(__builtin_fmaf(s[r0 + i], c_log2, -m_adj));
+      // two chains of single adds (packed f32 adds beside MFMAs cost more than the pairs they replace; the
+      // empty asm keeps the chain inside this chunk's MFMA gap instead of being sunk to the end of the tile)
+      float e = ps + x[0], o = x[1] + x[2];
+      e += x[3];
+      o += x[4];
+      e += x[5];
+      o += x[6];
+      e += x[7];
+      ps = e + o;
+      asm volatile("" : "+v"(ps));
+      // both halves of each word are written by the two conversions: the initial content is don't-care
+      int u0, u1;
+      asm("" : "=v"(u0));
+      asm("" : "=v"(u1));
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], u0, false), true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], u1, false), true);
+    };
+
+    // ---- prologue: S^T of tile 0, its mask and row maximum ----
+    f32x16 s_a[2], s_b[2];
+    {
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      s_a[0] = mfma_fp8_k64(k_frag(smem, 1), q1, mfma_fp8_k64(k_frag(smem, 0), q0, zero));
+      s_a[1] = mfma_fp8_k64(k_frag(smem, 3), q1, mfma_fp8_k64(k_frag(smem, 2), q0, zero));
+      if (tile_needs_mask(0)) apply_mask(0, s_a);
+      float mx = max_chunk(s_a[0], 0, -INFINITY);
+      mx = max_chunk(s_a[0], 8, mx);
+      mx = max_chunk(s_a[1], 0, mx);
+      mx = max_chunk(s_a[1], 8, mx);
+      rescale_if_needed(mx, true);
     }
-    if (t < num_tiles) tile_body(std::integral_constant<int, 0>{}, t);
+
+    // One pipeline step: tile t (scores in sc) is finished while the scores of tile t+1 are produced in sn.
+    // ST = t & 3 (ring stage of tile t), MASK: tile t+1 takes the mask code.  A wave issues in order, so the
+    // vector work is placed BETWEEN the MFMAs in program order (sched_barrier keeps the groups apart):
+    //   region A: 4 x { K fragment of the next MFMA, QK^T MFMA of tile t+1, exp2 / sum / e4m3 of 8 scores of tile t }
+    //   region B: 4 x { V^T fragment two MFMAs ahead, P.V MFMA of tile t, running maximum over 8 scores of tile t+1 }
+    auto step = [&](auto stage_c, auto mask_c, f32x16 (&sc)[2], f32x16 (&sn)[2], const int t) {
+      constexpr int ST = decltype(stage_c)::value;
+      constexpr bool MASK = decltype(mask_c)::value;
+      // table of tile t+4 -> the slot tile t's table used (read for the last time at step t-3)
+      if (wave == ST) make_tab(t + 4, ST);
+      // new rows for the ring: tile t+3 into the stage tile t-1 left (every wave passed the barrier of t-1)
+      dma_tile((ST + 3) & 3, (ST + 3) & 3);
+      __builtin_amdgcn_sched_barrier(0);
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const char* const kb = smem + ((ST + 1) & 3) * kF8KTile;  // tile t+1 (past the end: the last tile again)
+      int p8w[8];
+      float ps0 = 0.f, ps1 = 0.f;
+      // ---- region A ----
+      // group g: MFMA g-1 of QK^T (tile t+1) first, then the K fragment two MFMAs ahead, then the exp2 chunk g
+      // of tile t; the first chunk runs under the LDS latency of the first two fragments
+#define FI_F8_GROUP(nds)                                         \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             \
+  __builtin_amdgcn_sched_group_barrier(0x100, nds, 0);           \
+  __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);             \
+  __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);             \
+  __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);             \
+  __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);             \
+  __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);            \
+  __builtin_amdgcn_sched_barrier(0);
+      i32x8 kf0 = k_frag(kb, 0);
+      i32x8 kf1 = k_frag(kb, 1);
+      exp_chunk(sc[0], 0, p8w[0], p8w[1], ps0);
+      __builtin_amdgcn_sched_barrier(0);
+      sn[0] = mfma_fp8_k64(kf0, q0, zero);
+      kf0 = k_frag(kb, 2);
+      exp_chunk(sc[0], 8, p8w[2], p8w[3], ps1);
+      FI_F8_GROUP(2)
+      sn[0] = mfma_fp8_k64(kf1, q1, sn[0]);
+      kf1 = k_frag(kb, 3);
+      exp_chunk(sc[1], 0, p8w[4], p8w[5], ps0);
+      FI_F8_GROUP(2)
+      sn[1] = mfma_fp8_k64(kf0, q0, zero);
+      exp_chunk(sc[1], 8, p8w[6], p8w[7], ps1);
+      FI_F8_GROUP(0)
+#undef FI_F8_GROUP
+      sn[1] = mfma_fp8_k64(kf1, q1, sn[1]);
+      l_run += ps0 + ps1;
+      const i32x8 p8 = {p8w[0], p8w[1], p8w[2], p8w[3], p8w[4], p8w[5], p8w[6], p8w[7]};
+      // ---- region B ----  (the fourth QK^T MFMA runs under the first V^T fragment reads)
+      constexpr int VB = kF8VOff + ST * kF8KTile;  // V tile of stage ST; transposed reads r = 0..3 at rows 0 / 16 / 32 / 48
+      i32x2 va[4], vb[4];
+#define FI_F8_VREAD(dst, db)                        \
+  dst[0] = lds_tr8<VB + 0 * 2048>(v_rd[db]);        \
+  dst[1] = lds_tr8<VB + 1 * 2048>(v_rd[db]);        \
+  dst[2] = lds_tr8<VB + 2 * 2048>(v_rd[db]);        \
+  dst[3] = lds_tr8<VB + 3 * 2048>(v_rd[db]);
+#define FI_F8_VWAIT(n, w) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]))
+#define FI_F8_VFRAG(w) (i32x8{w[0][0], w[0][1], w[1][0], w[1][1], w[2][0], w[2][1], w[3][0], w[3][1]})
+      FI_F8_VREAD(va, 0)
+      FI_F8_VREAD(vb, 1)
+      if constexpr (MASK) apply_mask(t + 1, sn);
+      FI_F8_VWAIT(4, va);
+      o_acc[0] = mfma_fp8_k64(FI_F8_VFRAG(va), p8, o_acc[0]);
+      float mx = max_chunk(sn[0], 0, -INFINITY);
+      FI_F8_VREAD(va, 2)
+      __builtin_amdgcn_sched_barrier(0);
+      FI_F8_VWAIT(4, vb);
+      o_acc[1] = mfma_fp8_k64(FI_F8_VFRAG(vb), p8, o_acc[1]);
+      mx = max_chunk(sn[0], 8, mx);
+      FI_F8_VREAD(vb, 3)
+      __builtin_amdgcn_sched_barrier(0);
+      FI_F8_VWAIT(4, va);
+      o_acc[2] = mfma_fp8_k64(FI_F8_VFRAG(va), p8, o_acc[2]);
+      mx = max_chunk(sn[1], 0, mx);
+      __builtin_amdgcn_sched_barrier(0);
+      FI_F8_VWAIT(0, vb);
+      o_acc[3] = mfma_fp8_k64(FI_F8_VFRAG(vb), p8, o_acc[3]);
+      mx = max_chunk(sn[1], 8, mx);
+#undef FI_F8_VREAD
+#undef FI_F8_VWAIT
+#undef FI_F8_VFRAG
+      __builtin_amdgcn_sched_barrier(0);
+      rescale_if_needed(mx, t + 1 < num_tiles);
+      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // K of tile t+2 (and everything older) landed
+      __builtin_amdgcn_s_barrier();
+    };
+    auto refill_if_needed = [&](int t_first, int t_last) {
+      if (p.kv_indices && !(ids_cover(t_first + 4) && ids_cover(t_last + 4))) {  // uniform; rare
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tile = tile_base + min(t_first + 4, num_tiles - 1);
+        ids_base = (int)fast_div((uint32_t)max(min(tile * kTileKV, kv_len - 1), 0), p.page_div);
+        fill_ids();
+        __syncthreads();
+      }
+    };
+    using std::integral_constant;
+    using std::false_type;
+    using std::true_type;
+    int t = 0;
+    // bulk: four steps per trip (one per ring stage), the scores ping-pong between s_a and s_b
+    while (t + 4 <= num_tiles && !tile_needs_mask(t + 1) && !tile_needs_mask(t + 2) && !tile_needs_mask(t + 3) &&
+           !tile_needs_mask(t + 4)) {
+      refill_if_needed(t, t + 3);
+      step(integral_constant<int, 0>{}, false_type{}, s_a, s_b, t);
+      step(integral_constant<int, 1>{}, false_type{}, s_b, s_a, t + 1);
+      step(integral_constant<int, 2>{}, false_type{}, s_a, s_b, t + 2);
+      step(integral_constant<int, 3>{}, false_type{}, s_b, s_a, t + 3);
+      t += 4;
+    }
+    // remaining tiles (the diagonal / the partial last tile): one step at a time, mask code always in; the
+    // stage stays a compile-time constant (t is a multiple of 4 here)
+    for (; t < num_tiles; t += 4) {
+      refill_if_needed(t, t + 3);
+      step(integral_constant<int, 0>{}, true_type{}, s_a, s_b, t);
+      if (t + 1 < num_tiles) step(integral_constant<int, 1>{}, true_type{}, s_b, s_a, t + 1);
+      if (t + 2 < num_tiles) step(integral_constant<int, 2>{}, true_type{}, s_a, s_b, t + 2);
+      if (t + 3 < num_tiles) step(integral_constant<int, 3>{}, true_type{}, s_b, s_a, t + 3);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped extra tiles still land in the ring
+    __builtin_amdgcn_s_barrier();
   }
 
-  // ---- finalize: l_run carries the x448 of P, so O / l_run is already free of it ----
+  // ---- finalize: l_run carries the constant factor of P8, so O / l_run is free of it ----
   l_run += swap_halves(l_run);
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
   if (p.scale_v) inv *= p.scale_v[kv_head];
-  if (row_valid && split) {
-    const int64_t entry = p.merge_indptr ? (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk
-                                         : (int64_t)(qo_start + qo_idx) * p.num_kv_chunks + kv_chunk;
-    const int64_t ob = (entry * p.num_qo_heads + qo_head) * D;
+  const float lse_val = empty ? FI_NEG_INF : m_run + fast_log2(l_run) - kF8Log2Scale;
+  if (split) {
+    if (row_valid) {
+      const int64_t entry = p.merge_indptr ? (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk
+                                           : (int64_t)(qo_start + qo_idx) * p.num_kv_chunks + kv_chunk;
+      const int64_t ob = (entry * p.num_qo_heads + qo_head) * D;
 #pragma unroll
-    for (int db = 0; db < DBLK; ++db) {
+      for (int db = 0; db < DBLK; ++db) {
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int d0 = 32 * db + 8 * r4 + 4 * lh;
-        *(f32x4*)(p.tmp_o + ob + d0) = f32x4{o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv,
-                                             o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv};
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int d0 = 32 * db + 8 * r4 + 4 * lh;
+          *(f32x4*)(p.tmp_o + ob + d0) = f32x4{o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv,
+                                               o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv};
+        }
       }
+      if (lh == 0) p.tmp_lse[entry * p.num_qo_heads + qo_head] = lse_val;
     }
+    return;
+  }
+  // Output through LDS: the wave's 32 x 128 block as 16-bit rows of 256 bytes (16-byte chunks XOR-swizzled
+  // by the row), read back as whole rows -- 16 bytes per lane, 4 rows per store instruction.  Four packed
+  // rows of one token are adjacent heads, i.e. adjacent 256-byte rows of the output tensor.
+  {
+    char* const region = smem + wave * 8192;            // the K ring is idle now
+    int64_t* const rowtab = (int64_t*)(smem + kF8TabOff) + wave * 32;
     if (lh == 0)
-      p.tmp_lse[entry * p.num_qo_heads + qo_head] =
-          empty ? FI_NEG_INF : m_run + fast_log2(l_run) - 8.807354922057604f;
-  } else if (row_valid) {
-    const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
+      rowtab[lq] = row_valid ? ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D : (int64_t)-1;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int d0 = 32 * db + 8 * r4 + 4 * lh;
         const uint32_t w0 = pack2<OUT16>(o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv);
         const uint32_t w1 = pack2<OUT16>(o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv);
-        *(u32x2*)((uint16_t*)p.o + ob + d0) = u32x2{w0, w1};
+        *(u32x2*)(region + lq * 256 + (((4 * db + r4) ^ (lq & 15)) << 4) + 8 * lh) = u32x2{w0, w1};
       }
     }
-    if (p.lse && lh == 0)
-      p.lse[(int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head] =
-          empty ? FI_NEG_INF : m_run + fast_log2(l_run) - 8.807354922057604f;
+    __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
+    const int rr = lane >> 4, ch = lane & 15;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int row = 4 * ps + rr;
+      const u32x4 w = *(const u32x4*)(region + row * 256 + ((ch ^ (row & 15)) << 4));
+      const int64_t ob = rowtab[row];
+      if (ob >= 0) *(u32x4*)((uint16_t*)p.o + ob + 8 * ch) = w;
+    }
+    if (p.lse && lh == 0 && row_valid)
+      p.lse[(int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head] = lse_val;
   }
 }
 

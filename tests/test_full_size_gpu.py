@@ -20,7 +20,9 @@ def _per_head_quant_gpu(x):
     """per_head_symmetric_quant (ref: tests/attention/test_hopper_fp8_attention.py:12-41) on device tensors
     [n, H, D]; bit-identical to oracle.attention_ref.per_head_symmetric_quant (checked below on a slice)."""
     amax = x.abs().amax(dim=(0, 2)).to(torch.float32)
-    s = torch.clamp(amax / 448.0, min=1e-6)
+    # the scale is formed on the host: torch divides a device tensor by a python scalar as a multiplication by
+    # its reciprocal, which is one ulp off the true quotient the reference (and the oracle) compute
+    s = torch.clamp(amax.cpu() / 448.0, min=1e-6).to(x.device)
     return torch.clamp(x.float() / s.view(1, -1, 1), min=-448.0, max=448.0).to(torch.float8_e4m3fn), s
 
 

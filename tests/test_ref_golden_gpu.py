@@ -200,8 +200,9 @@ def test_variable_length_merge_states_matches_oracle_ragged():
         keep = [r for r, c in enumerate(counts) if c > 0]
         vo = torch.empty(len(counts), h, d, dtype=dt, device=DEV)
         so = torch.empty(len(counts), h, dtype=torch.float32, device=DEV)
+        v_d, s_d, ip_d = v.to(DEV), s.to(DEV), indptr.to(DEV)  # kept alive across the asynchronous launch
         _lib.check(_lib.lib().fi_variable_length_merge_states(
-            v.to(DEV).data_ptr(), s.to(DEV).data_ptr(), indptr.to(DEV).data_ptr(), vo.data_ptr(), so.data_ptr(),
+            v_d.data_ptr(), s_d.data_ptr(), ip_d.data_ptr(), vo.data_ptr(), so.data_ptr(),
             len(counts), h, d, _lib.fi_dtype(dt), _lib.fi_dtype(dt), _lib.current_stream(vo.device)), "vlms")
         torch.cuda.synchronize()
         for r in keep:
