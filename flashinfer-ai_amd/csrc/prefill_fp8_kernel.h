@@ -34,6 +34,12 @@
 
 #include "prefill_fp8_v1_kernel.h"
 
+#ifndef FI_PF8_KO
+#define FI_PF8_KO 0  // timing experiments only (results are wrong), bit mask: 1 no exp2, 2 no DMA in the steps,
+                     // 4 no barrier / vmcnt wait, 8 no P.V MFMAs, 16 no QK^T MFMAs, 32 no rescale check,
+                     // 64 one workgroup per CU (LDS padded)
+#endif
+
 namespace fi {
 
 constexpr int kF8Stages = 4;        // ring depth (K and V each): tile t+1 / t read, t+2 landed, t+3 in flight
@@ -67,7 +73,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
   // ONE static array for every LDS object: the compiler separates an LDS-DMA target from an LDS read by
   // constant offsets (and index ranges) inside one object; with a second object, or unbounded indices, it
   // puts s_waitcnt vmcnt(0) in front of the reads and the prefetch is gone
-  __shared__ __attribute__((aligned(1024))) char smem[kF8Smem];
+  __shared__ __attribute__((aligned(1024))) char smem[kF8Smem + ((FI_PF8_KO & 64) ? 40960 : 0)];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -232,16 +238,25 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       const int p0 = (int)fast_div((uint32_t)k0, p.page_div), p1 = (int)fast_div((uint32_t)k1, p.page_div);
       return p0 >= ids_base && p1 - ids_base < kF8Ids;
     };
-    // DMA of tile t_rel's K and V rows into ring stage `stage` (row offsets from table slot `slot`)
-    auto dma_tile = [&](int slot, int stage) {
-      const uint64_t off0 = tab[slot * kTileKV + st_row];
-      const uint64_t off1 = tab[slot * kTileKV + st_row + 32];
+    // DMA of a tile's K and V rows into ring stage `stage`: the row offsets are read from table slot `slot` first
+    // (dma_offsets, early in a step) and the four pieces are issued later (dma_issue), so that the LDS latency of
+    // the table read does not sit at the top of the step
+    auto dma_offsets = [&](int slot, uint64_t& off0, uint64_t& off1) {
+      off0 = tab[slot * kTileKV + st_row];
+      off1 = tab[slot * kTileKV + st_row + 32];
+    };
+    auto dma_issue = [&](int stage, uint64_t off0, uint64_t off1) {
       char* const kdst = smem + stage * kF8KTile + wave * 1024;
       char* const vdst = kdst + kF8VOff;
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off0), (f8_lds_void*)(kdst), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off1), (f8_lds_void*)(kdst + 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off0), (f8_lds_void*)(vdst), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off1), (f8_lds_void*)(vdst + 4096), 16, 0, 0);
+    };
+    auto dma_tile = [&](int slot, int stage) {
+      uint64_t off0, off1;
+      dma_offsets(slot, off0, off1);
+      dma_issue(stage, off0, off1);
     };
 
     fill_ids();
@@ -280,27 +295,31 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       mx = fmaxf(fmaxf(mx, s[r0 + 4]), s[r0 + 5]);
       return fmaxf(fmaxf(mx, s[r0 + 6]), s[r0 + 7]);
     };
-    // moves the reference exponent only when a row outgrew it by more than 2^kF8Thr (rare path)
-    auto rescale_if_needed = [&](float mx, const bool real_tile) {
+    // The reference exponent moves only when a row outgrew it by more than 2^kF8Thr (rare).  The decision needs
+    // the row maximum only (rescale_decide, computed under the P.V MFMAs); the O registers are scaled after the
+    // last P.V MFMA of the tile (rescale_apply).
+    auto rescale_decide = [&](float mx, const bool real_tile, float& m_true) {
       mx = fmaxf(mx, swap_halves(mx));
       // scores of a tile past the end (the pipeline runs one tile ahead) must not move the exponent
-      const float m_true = real_tile ? fmaxf(m_run, mx * c_log2) : m_run;  // c_log2 > 0
-      if (__any(m_true - m_run > kF8Thr)) {
-        const float alpha = fast_exp2(m_run - m_true);
-        m_run = m_true;
-        m_adj = m_true - kF8Log2Scale;
-        l_run *= alpha;
+      m_true = real_tile ? fmaxf(m_run, mx * c_log2) : m_run;  // c_log2 > 0
+      return (FI_PF8_KO & 32) ? false : (bool)__any(m_true - m_run > kF8Thr);
+    };
+    auto rescale_apply = [&](float m_true) {
+      const float alpha = fast_exp2(m_run - m_true);
+      m_run = m_true;
+      m_adj = m_true - kF8Log2Scale;
+      l_run *= alpha;
 #pragma unroll
-        for (int db = 0; db < DBLK; ++db)
+      for (int db = 0; db < DBLK; ++db)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
-      }
+        for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
     };
     // exp2 of registers r0 .. r0 + 7 of a score block: their sum and their e4m3 image (two words of the B operand)
     auto exp_chunk = [&](const f32x16& s, int r0, int& w0, int& w1, float& ps) {
       float x[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) x[i] = fast_exp2(__builtin_fmaf(s[r0 + i], c_log2, -m_adj));
+      for (int i = 0; i < 8; ++i)
+        x[i] = (FI_PF8_KO & 1) ? __builtin_fmaf(s[r0 + i], c_log2, -m_adj) : fast_exp2(__builtin_fmaf(s[r0 + i], c_log2, -m_adj));
       // two chains of single adds (packed f32 adds beside MFMAs cost more than the pairs they replace; the
       // empty asm keeps the chain inside this chunk's MFMA gap instead of being sunk to the end of the tile)
       float e = ps + x[0], o = x[1] + x[2];
@@ -330,7 +349,8 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       mx = max_chunk(s_a[0], 8, mx);
       mx = max_chunk(s_a[1], 0, mx);
       mx = max_chunk(s_a[1], 8, mx);
-      rescale_if_needed(mx, true);
+      float m_true;
+      if (rescale_decide(mx, true, m_true)) rescale_apply(m_true);
     }
 
     // One pipeline step: tile t (scores in sc) is finished while the scores of tile t+1 are produced in sn.
@@ -343,13 +363,26 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       constexpr bool MASK = decltype(mask_c)::value;
       // table of tile t+4 -> the slot tile t's table used (read for the last time at step t-3)
       if (wave == ST) make_tab(t + 4, ST);
-      // new rows for the ring: tile t+3 into the stage tile t-1 left (every wave passed the barrier of t-1)
-      dma_tile((ST + 3) & 3, (ST + 3) & 3);
-      __builtin_amdgcn_sched_barrier(0);
+      // row offsets of tile t+3 (its DMA is issued inside region A, after the table read has returned)
+      uint64_t off0, off1;
+      dma_offsets((ST + 3) & 3, off0, off1);
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const char* const kb = smem + ((ST + 1) & 3) * kF8KTile;  // tile t+1 (past the end: the last tile again)
       int p8w[8];
       float ps0 = 0.f, ps1 = 0.f;
+      // V^T fragments of the first two P.V MFMAs: V of tile t landed before the last barrier, so they are read
+      // now and wait in registers through region A
+      constexpr int VB = kF8VOff + ST * kF8KTile;  // V tile of stage ST; transposed reads r = 0..3 at rows 0 / 16 / 32 / 48
+      i32x2 va[4], vb[4];
+#define FI_F8_VREAD(dst, db)                        \
+  dst[0] = lds_tr8<VB + 0 * 2048>(v_rd[db]);        \
+  dst[1] = lds_tr8<VB + 1 * 2048>(v_rd[db]);        \
+  dst[2] = lds_tr8<VB + 2 * 2048>(v_rd[db]);        \
+  dst[3] = lds_tr8<VB + 3 * 2048>(v_rd[db]);
+#define FI_F8_VWAIT(n, w) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]))
+#define FI_F8_VFRAG(w) (i32x8{w[0][0], w[0][1], w[1][0], w[1][1], w[2][0], w[2][1], w[3][0], w[3][1]})
+      FI_F8_VREAD(va, 0)
+      FI_F8_VREAD(vb, 1)
       // ---- region A ----
       // group g: MFMA g-1 of QK^T (tile t+1) first, then the K fragment two MFMAs ahead, then the exp2 chunk g
       // of tile t; the first chunk runs under the LDS latency of the first two fragments
@@ -362,62 +395,65 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
   __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);             \
   __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);            \
   __builtin_amdgcn_sched_barrier(0);
+#define FI_F8_QK(a, b, c) ((FI_PF8_KO & 16) ? (c) : mfma_fp8_k64(a, b, c))
+#define FI_F8_PV(a, b, c) ((FI_PF8_KO & 8) ? (c) : mfma_fp8_k64(a, b, c))
       i32x8 kf0 = k_frag(kb, 0);
       i32x8 kf1 = k_frag(kb, 1);
+      __builtin_amdgcn_sched_barrier(0);  // every LDS read of the step's head is in flight before the first chunk
       exp_chunk(sc[0], 0, p8w[0], p8w[1], ps0);
+      // new rows for the ring: tile t+3 into the stage tile t-1 left (every wave passed the barrier of t-1)
+      if (!(FI_PF8_KO & 2)) dma_issue((ST + 3) & 3, off0, off1);
       __builtin_amdgcn_sched_barrier(0);
-      sn[0] = mfma_fp8_k64(kf0, q0, zero);
+      sn[0] = FI_F8_QK(kf0, q0, zero);
       kf0 = k_frag(kb, 2);
       exp_chunk(sc[0], 8, p8w[2], p8w[3], ps1);
       FI_F8_GROUP(2)
-      sn[0] = mfma_fp8_k64(kf1, q1, sn[0]);
+      sn[0] = FI_F8_QK(kf1, q1, sn[0]);
       kf1 = k_frag(kb, 3);
       exp_chunk(sc[1], 0, p8w[4], p8w[5], ps0);
       FI_F8_GROUP(2)
-      sn[1] = mfma_fp8_k64(kf0, q0, zero);
+      sn[1] = FI_F8_QK(kf0, q0, zero);
       exp_chunk(sc[1], 8, p8w[6], p8w[7], ps1);
       FI_F8_GROUP(0)
 #undef FI_F8_GROUP
-      sn[1] = mfma_fp8_k64(kf1, q1, sn[1]);
+      sn[1] = FI_F8_QK(kf1, q1, sn[1]);
+      if (FI_PF8_KO & 16) asm volatile("" : "+v"(kf0), "+v"(kf1));
       l_run += ps0 + ps1;
       const i32x8 p8 = {p8w[0], p8w[1], p8w[2], p8w[3], p8w[4], p8w[5], p8w[6], p8w[7]};
-      // ---- region B ----  (the fourth QK^T MFMA runs under the first V^T fragment reads)
-      constexpr int VB = kF8VOff + ST * kF8KTile;  // V tile of stage ST; transposed reads r = 0..3 at rows 0 / 16 / 32 / 48
-      i32x2 va[4], vb[4];
-#define FI_F8_VREAD(dst, db)                        \
-  dst[0] = lds_tr8<VB + 0 * 2048>(v_rd[db]);        \
-  dst[1] = lds_tr8<VB + 1 * 2048>(v_rd[db]);        \
-  dst[2] = lds_tr8<VB + 2 * 2048>(v_rd[db]);        \
-  dst[3] = lds_tr8<VB + 3 * 2048>(v_rd[db]);
-#define FI_F8_VWAIT(n, w) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]))
-#define FI_F8_VFRAG(w) (i32x8{w[0][0], w[0][1], w[1][0], w[1][1], w[2][0], w[2][1], w[3][0], w[3][1]})
-      FI_F8_VREAD(va, 0)
-      FI_F8_VREAD(vb, 1)
+      // ---- region B ----  (the fourth QK^T MFMA runs under the wait for the first V^T fragment)
       if constexpr (MASK) apply_mask(t + 1, sn);
       FI_F8_VWAIT(4, va);
-      o_acc[0] = mfma_fp8_k64(FI_F8_VFRAG(va), p8, o_acc[0]);
+      o_acc[0] = FI_F8_PV(FI_F8_VFRAG(va), p8, o_acc[0]);
       float mx = max_chunk(sn[0], 0, -INFINITY);
+      mx = max_chunk(sn[0], 8, mx);
       FI_F8_VREAD(va, 2)
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_VWAIT(4, vb);
-      o_acc[1] = mfma_fp8_k64(FI_F8_VFRAG(vb), p8, o_acc[1]);
-      mx = max_chunk(sn[0], 8, mx);
+      o_acc[1] = FI_F8_PV(FI_F8_VFRAG(vb), p8, o_acc[1]);
+      mx = max_chunk(sn[1], 0, mx);
+      mx = max_chunk(sn[1], 8, mx);
       FI_F8_VREAD(vb, 3)
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_VWAIT(4, va);
-      o_acc[2] = mfma_fp8_k64(FI_F8_VFRAG(va), p8, o_acc[2]);
-      mx = max_chunk(sn[1], 0, mx);
+      o_acc[2] = FI_F8_PV(FI_F8_VFRAG(va), p8, o_acc[2]);
+      // the decision of the deferred rescale runs under the last two MFMAs; only its (rare) application waits for them
+      float m_true;
+      const bool resc = rescale_decide(mx, t + 1 < num_tiles, m_true);
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_VWAIT(0, vb);
-      o_acc[3] = mfma_fp8_k64(FI_F8_VFRAG(vb), p8, o_acc[3]);
-      mx = max_chunk(sn[1], 8, mx);
+      o_acc[3] = FI_F8_PV(FI_F8_VFRAG(vb), p8, o_acc[3]);
+      if (FI_PF8_KO & 8) asm volatile("" :: "v"(p8), "v"(va[0]), "v"(vb[0]));
 #undef FI_F8_VREAD
 #undef FI_F8_VWAIT
 #undef FI_F8_VFRAG
+#undef FI_F8_QK
+#undef FI_F8_PV
       __builtin_amdgcn_sched_barrier(0);
-      rescale_if_needed(mx, t + 1 < num_tiles);
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // K of tile t+2 (and everything older) landed
-      __builtin_amdgcn_s_barrier();
+      if (resc) rescale_apply(m_true);
+      if (!(FI_PF8_KO & 4)) {
+        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // K of tile t+2 (and everything older) landed
+        __builtin_amdgcn_s_barrier();
+      }
     };
     auto refill_if_needed = [&](int t_first, int t_last) {
       if (p.kv_indices && !(ids_cover(t_first + 4) && ids_cover(t_last + 4))) {  // uniform; rare
@@ -432,19 +468,22 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
     using std::integral_constant;
     using std::false_type;
     using std::true_type;
+    // unmasked prefix: tiles 1 .. n_plain need no mask code (both conditions of tile_needs_mask are monotone in the
+    // tile index), so steps 0 .. n_plain - 1 run the plain body; found once, the loop conditions are one compare
+    int n_plain = 0;
+    while (n_plain + 1 < num_tiles && !tile_needs_mask(n_plain + 1)) ++n_plain;
+    const int bulk_end = n_plain & ~3;  // four plain steps per trip
+    // page-id window: the first step whose table (tile t + 4) leaves the window, checked once per trip
     int t = 0;
-    // bulk: four steps per trip (one per ring stage), the scores ping-pong between s_a and s_b
-    while (t + 4 <= num_tiles && !tile_needs_mask(t + 1) && !tile_needs_mask(t + 2) && !tile_needs_mask(t + 3) &&
-           !tile_needs_mask(t + 4)) {
+    for (; t < bulk_end; t += 4) {
       refill_if_needed(t, t + 3);
       step(integral_constant<int, 0>{}, false_type{}, s_a, s_b, t);
       step(integral_constant<int, 1>{}, false_type{}, s_b, s_a, t + 1);
       step(integral_constant<int, 2>{}, false_type{}, s_a, s_b, t + 2);
       step(integral_constant<int, 3>{}, false_type{}, s_b, s_a, t + 3);
-      t += 4;
     }
-    // remaining tiles (the diagonal / the partial last tile): one step at a time, mask code always in; the
-    // stage stays a compile-time constant (t is a multiple of 4 here)
+    // remaining tiles (the diagonal / the partial last tile): mask code always in; the stage stays a compile-time
+    // constant (t is a multiple of 4 here)
     for (; t < num_tiles; t += 4) {
       refill_if_needed(t, t + 3);
       step(integral_constant<int, 0>{}, true_type{}, s_a, s_b, t);

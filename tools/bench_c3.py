@@ -9,7 +9,11 @@ from bench_prefill import run
 
 if __name__ == "__main__":
     tag = "C3 fp8 (v1)" if os.environ.get("FI_PREFILL_FP8_V1") == "1" else "C3 fp8 (v2)"
+    if os.environ.get("FI_MI355_LIB"):
+        tag += " " + os.path.basename(os.environ["FI_MI355_LIB"]).replace("libfi_prefill_fp8_inst_", "KO=").replace(".so", "")
     for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
         run(torch.float8_e4m3fn, tag=tag)
+    if len(sys.argv) > 2 and sys.argv[2] == "quick":
+        sys.exit(0)
     run(torch.float8_e4m3fn, causal=False, tag=tag + " non-causal")
     run(torch.float8_e4m3fn, b=4, qo=8192, kv=8192, tag=tag + " bs4 8k/8k")
