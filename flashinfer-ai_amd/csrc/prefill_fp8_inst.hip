@@ -8,7 +8,11 @@ namespace fi {
 
 template <int OUT16>
 static hipError_t launch_v2(const PrefillKernelParams& p, int grid, hipStream_t stream) {
-  batch_prefill_fp8_kernel<OUT16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+  // group sizes 1 / 2 / 4: one query head per wave, logit scale in a scalar register (see the kernel)
+  if (p.group_size == 1 || p.group_size == 2 || p.group_size == 4)
+    batch_prefill_fp8_kernel<OUT16, true><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+  else
+    batch_prefill_fp8_kernel<OUT16, false><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
   return hipGetLastError();
 }
 

@@ -40,7 +40,25 @@
                      // 64 one workgroup per CU (LDS padded)
 #endif
 
+#ifndef FI_PF8_ASM_MFMA
+#define FI_PF8_ASM_MFMA 1  // the steps' MFMAs as asm volatile statements: they stay where the source puts them
+#endif
+
 namespace fi {
+
+// MFMA as an asm statement (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 x e4m3, unit block scales).  The compiler moves
+// builtin MFMAs freely -- across the step barrier and into back-to-back bursts -- while the pipeline below wants each
+// one between two blocks of vector work.  What the compiler no longer does for these statements (guide 5.7): hazard
+// padding -- the leading s_nop covers a vector write of an operand right before the statement; every reader of a
+// result sits at least one MFMA (64 cycles) later in program order (noted at each use).
+__device__ __forceinline__ void mfma_fp8_k64_asm(f32x16& c, const i32x8& a, const i32x8& b, int unit) {
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+               : "+v"(c) : "v"(a), "v"(b), "v"(unit));
+}
+__device__ __forceinline__ void mfma_fp8_k64_asm_zero(f32x16& c, const i32x8& a, const i32x8& b, int unit) {
+  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
+               : "=v"(c) : "v"(a), "v"(b), "v"(unit));
+}
 
 constexpr int kF8Stages = 4;        // ring depth (K and V each): tile t+1 / t read, t+2 landed, t+3 in flight
 constexpr int kF8KTile = kTileKV * 128;
@@ -66,7 +84,11 @@ __device__ __forceinline__ i32x2 lds_tr8(int addr) {
 typedef __attribute__((address_space(3))) void f8_lds_void;
 typedef const __attribute__((address_space(1))) void f8_gbl_void;
 
-template <int OUT16>
+// UNI: GQA group size 1, 2 or 4 -- every wave then holds rows of ONE query head (wave w: head w % G, 32 consecutive
+// tokens), so the logit scale c = sm_scale * scale_q[head] * scale_k[kv head] * log2 e is wave-uniform and sits in a
+// scalar register: exp2's argument fma(s, c, -m) then reads two vector registers instead of three (a vector
+// instruction with three distinct vector sources issues at half rate: tools/ubench_issue2 measurements).
+template <int OUT16, bool UNI>
 __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
   constexpr int D = 128;
   constexpr int DBLK = D / 32;
@@ -121,8 +143,10 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
   }
   const int G = p.group_size;
   const int packed_len = qo_len * G;
-  const int row0 = q_tile * kTileQ + wave * 32;
-  const int pr = row0 + lq;
+  // packed row (qo_idx * G + head) of this lane inside the workgroup's 128-row tile
+  const int row_in_tile = UNI ? ((wave / G) * 32 + lq) * G + (wave % G) : wave * 32 + lq;
+  const int row0 = q_tile * kTileQ + (UNI ? (wave / G) * 32 * G : wave * 32);  // the wave's first packed row
+  const int pr = q_tile * kTileQ + row_in_tile;
   const bool row_valid = pr < packed_len;
   const int prc = row_valid ? pr : (packed_len > 0 ? packed_len - 1 : 0);
   const int qo_idx = (int)fast_div((uint32_t)prc, p.group_div);
@@ -146,7 +170,9 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
   float qk_scale = p.sm_scale;
   if (p.scale_q) qk_scale *= p.scale_q[qo_head];
   if (p.scale_k) qk_scale *= p.scale_k[kv_head];
-  const float c_log2 = qk_scale * kLog2e;
+  const float c_lane = qk_scale * kLog2e;
+  // wave-uniform copy (valid with UNI): a scalar register
+  const float c_uni = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c_lane)));
 
   int kv_end = kv_len;
   if (p.causal) {
@@ -266,8 +292,8 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
     dma_tile(0, 0);
     dma_tile(1, 1);
     dma_tile(2, 2);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // tiles 0 and 1 have landed (tile 2: 4 pieces in flight)
-    __builtin_amdgcn_s_barrier();
+    // tiles 0 and 1 have landed (tile 2: 4 pieces in flight); wait + barrier as one statement (see the step)
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
 
     // ---- building blocks ----
     const i32x8 q0 = qf[0], q1 = qf[1];
@@ -288,52 +314,57 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
           s[kbk][r] = rel <= span ? s[kbk][r] : -INFINITY;
         }
     };
-    // running maximum over registers r0 .. r0 + 7 of a score block
-    auto max_chunk = [&](const f32x16& s, int r0, float mx) {
-      mx = fmaxf(fmaxf(mx, s[r0]), s[r0 + 1]);
-      mx = fmaxf(fmaxf(mx, s[r0 + 2]), s[r0 + 3]);
-      mx = fmaxf(fmaxf(mx, s[r0 + 4]), s[r0 + 5]);
-      return fmaxf(fmaxf(mx, s[r0 + 6]), s[r0 + 7]);
+    // exact row maximum of a score tile (rare path only)
+    auto row_max = [&](const f32x16 (&s)[2]) {
+#define FI_F8_MAX8(v, r) fmaxf(fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 2], v[r + 3])), fmaxf(fmaxf(v[r + 4], v[r + 5]), fmaxf(v[r + 6], v[r + 7])))
+      const float mx = fmaxf(fmaxf(FI_F8_MAX8(s[0], 0), FI_F8_MAX8(s[0], 8)), fmaxf(FI_F8_MAX8(s[1], 0), FI_F8_MAX8(s[1], 8)));
+#undef FI_F8_MAX8
+      return fmaxf(mx, swap_halves(mx));
     };
-    // The reference exponent moves only when a row outgrew it by more than 2^kF8Thr (rare).  The decision needs
-    // the row maximum only (rescale_decide, computed under the P.V MFMAs); the O registers are scaled after the
-    // last P.V MFMA of the tile (rescale_apply).
-    auto rescale_decide = [&](float mx, const bool real_tile, float& m_true) {
-      mx = fmaxf(mx, swap_halves(mx));
-      // scores of a tile past the end (the pipeline runs one tile ahead) must not move the exponent
-      m_true = real_tile ? fmaxf(m_run, mx * c_log2) : m_run;  // c_log2 > 0
-      return (FI_PF8_KO & 32) ? false : (bool)__any(m_true - m_run > kF8Thr);
-    };
-    auto rescale_apply = [&](float m_true) {
+    // Deferred reference exponent WITHOUT a per-tile row maximum: the probabilities of a tile are formed against
+    // the current exponent m_run as P'' = 2^(c s - m_run) x 448 / 2^kF8Thr; e4m3 holds them as long as P'' <= 448.
+    // The sums over 8 probabilities (needed for the row sum anyway) bound every term, so "some chunk sum > 448" is
+    // the (conservative) overflow test.  Only then -- the first tile of a row, or a row maximum that grew by more
+    // than ~2^kF8Thr -- the exact maximum of the tile is taken, O and the row sum are rescaled to it (rescale_to)
+    // and the tile's probabilities are formed again.
+    auto rescale_to = [&](float m_true) {
       const float alpha = fast_exp2(m_run - m_true);
       m_run = m_true;
       m_adj = m_true - kF8Log2Scale;
       l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+      // whole-vector statements, no loop: in a block the compiler treats as cold a loop may stay rolled, and a
+      // runtime index would push the accumulators into scratch memory for the whole kernel
+      o_acc[0] = o_acc[0] * alpha;
+      o_acc[1] = o_acc[1] * alpha;
+      o_acc[2] = o_acc[2] * alpha;
+      o_acc[3] = o_acc[3] * alpha;
     };
+    const float c_exp = UNI ? c_uni : c_lane;
+    // exp2 argument c s - m_adj.  UNI: c from a SCALAR register, so the instruction reads two vector registers
+    // and issues at full rate
+    // (the readfirstlane is an asm statement: as a builtin the compiler pushes it through the multiplications that
+    // form c, and the product -- there is no scalar f32 multiply -- ends up in a vector register again)
+    float c_sreg = c_lane;
+    if constexpr (UNI) asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(c_sreg) : "v"(c_lane));
+    auto exp_arg = [&](float sv) { return __builtin_fmaf(sv, UNI ? c_sreg : c_lane, -m_adj); };
     // exp2 of registers r0 .. r0 + 7 of a score block: their sum and their e4m3 image (two words of the B operand)
-    auto exp_chunk = [&](const f32x16& s, int r0, int& w0, int& w1, float& ps) {
-      float x[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-        x[i] = (FI_PF8_KO & 1) ? __builtin_fmaf(s[r0 + i], c_log2, -m_adj) : fast_exp2(__builtin_fmaf(s[r0 + i], c_log2, -m_adj));
+    auto exp_chunk = [&](const f32x16& s, int r0, int& w0, int& w1, float& cs) {
+#define FI_F8_EXP(i) ((FI_PF8_KO & 1) ? exp_arg(s[r0 + i]) : fast_exp2(exp_arg(s[r0 + i])))
+      const float x[8] = {FI_F8_EXP(0), FI_F8_EXP(1), FI_F8_EXP(2), FI_F8_EXP(3), FI_F8_EXP(4), FI_F8_EXP(5), FI_F8_EXP(6), FI_F8_EXP(7)};
+#undef FI_F8_EXP
       // two chains of single adds (packed f32 adds beside MFMAs cost more than the pairs they replace; the
       // empty asm keeps the chain inside this chunk's MFMA gap instead of being sunk to the end of the tile)
-      float e = ps + x[0], o = x[1] + x[2];
-      e += x[3];
-      o += x[4];
-      e += x[5];
-      o += x[6];
-      e += x[7];
-      ps = e + o;
-      asm volatile("" : "+v"(ps));
+      float e = x[0] + x[1], o = x[2] + x[3];
+      e += x[4];
+      o += x[5];
+      e += x[6];
+      o += x[7];
+      cs = e + o;
+      asm volatile("" : "+v"(cs));
       // both halves of each word are written by the two conversions: the initial content is don't-care
-      int u0, u1;
-      asm("" : "=v"(u0));
-      asm("" : "=v"(u1));
+      int u0, u1;  // volatile: identical empty statements would otherwise be merged into one value (and copied)
+      asm volatile("" : "=v"(u0));
+      asm volatile("" : "=v"(u1));
       w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], u0, false), true);
       w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], u1, false), true);
     };
@@ -345,12 +376,6 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       s_a[0] = mfma_fp8_k64(k_frag(smem, 1), q1, mfma_fp8_k64(k_frag(smem, 0), q0, zero));
       s_a[1] = mfma_fp8_k64(k_frag(smem, 3), q1, mfma_fp8_k64(k_frag(smem, 2), q0, zero));
       if (tile_needs_mask(0)) apply_mask(0, s_a);
-      float mx = max_chunk(s_a[0], 0, -INFINITY);
-      mx = max_chunk(s_a[0], 8, mx);
-      mx = max_chunk(s_a[1], 0, mx);
-      mx = max_chunk(s_a[1], 8, mx);
-      float m_true;
-      if (rescale_decide(mx, true, m_true)) rescale_apply(m_true);
     }
 
     // One pipeline step: tile t (scores in sc) is finished while the scores of tile t+1 are produced in sn.
@@ -369,7 +394,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const char* const kb = smem + ((ST + 1) & 3) * kF8KTile;  // tile t+1 (past the end: the last tile again)
       int p8w[8];
-      float ps0 = 0.f, ps1 = 0.f;
+      float cs0, cs1, cs2, cs3;
       // V^T fragments of the first two P.V MFMAs: V of tile t landed before the last barrier, so they are read
       // now and wait in registers through region A
       constexpr int VB = kF8VOff + ST * kF8KTile;  // V tile of stage ST; transposed reads r = 0..3 at rows 0 / 16 / 32 / 48
@@ -395,65 +420,75 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
   __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);             \
   __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);            \
   __builtin_amdgcn_sched_barrier(0);
-#define FI_F8_QK(a, b, c) ((FI_PF8_KO & 16) ? (c) : mfma_fp8_k64(a, b, c))
-#define FI_F8_PV(a, b, c) ((FI_PF8_KO & 8) ? (c) : mfma_fp8_k64(a, b, c))
+      int unit = 0x7F7F7F7F;
+      asm volatile("" : "+v"(unit));
+#if FI_PF8_ASM_MFMA
+#define FI_F8_QK0(dst, a, b) if (!(FI_PF8_KO & 16)) mfma_fp8_k64_asm_zero(dst, a, b, unit)
+#define FI_F8_QK1(dst, a, b) if (!(FI_PF8_KO & 16)) mfma_fp8_k64_asm(dst, a, b, unit)
+#define FI_F8_PV(dst, a, b) if (!(FI_PF8_KO & 8)) mfma_fp8_k64_asm(dst, a, b, unit)
+#else
+#define FI_F8_QK0(dst, a, b) if (!(FI_PF8_KO & 16)) dst = mfma_fp8_k64(a, b, zero)
+#define FI_F8_QK1(dst, a, b) if (!(FI_PF8_KO & 16)) dst = mfma_fp8_k64(a, b, dst)
+#define FI_F8_PV(dst, a, b) if (!(FI_PF8_KO & 8)) dst = mfma_fp8_k64(a, b, dst)
+#endif
       i32x8 kf0 = k_frag(kb, 0);
       i32x8 kf1 = k_frag(kb, 1);
       __builtin_amdgcn_sched_barrier(0);  // every LDS read of the step's head is in flight before the first chunk
-      exp_chunk(sc[0], 0, p8w[0], p8w[1], ps0);
+      exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
       // new rows for the ring: tile t+3 into the stage tile t-1 left (every wave passed the barrier of t-1)
       if (!(FI_PF8_KO & 2)) dma_issue((ST + 3) & 3, off0, off1);
       __builtin_amdgcn_sched_barrier(0);
-      sn[0] = FI_F8_QK(kf0, q0, zero);
+      FI_F8_QK0(sn[0], kf0, q0);
       kf0 = k_frag(kb, 2);
-      exp_chunk(sc[0], 8, p8w[2], p8w[3], ps1);
+      exp_chunk(sc[0], 8, p8w[2], p8w[3], cs1);
       FI_F8_GROUP(2)
-      sn[0] = FI_F8_QK(kf1, q1, sn[0]);
+      FI_F8_QK1(sn[0], kf1, q1);
       kf1 = k_frag(kb, 3);
-      exp_chunk(sc[1], 0, p8w[4], p8w[5], ps0);
+      exp_chunk(sc[1], 0, p8w[4], p8w[5], cs2);
       FI_F8_GROUP(2)
-      sn[1] = FI_F8_QK(kf0, q0, zero);
-      exp_chunk(sc[1], 8, p8w[6], p8w[7], ps1);
+      FI_F8_QK0(sn[1], kf0, q0);
+      exp_chunk(sc[1], 8, p8w[6], p8w[7], cs3);
       FI_F8_GROUP(0)
 #undef FI_F8_GROUP
-      sn[1] = FI_F8_QK(kf1, q1, sn[1]);
+      FI_F8_QK1(sn[1], kf1, q1);
       if (FI_PF8_KO & 16) asm volatile("" : "+v"(kf0), "+v"(kf1));
-      l_run += ps0 + ps1;
+      __builtin_amdgcn_sched_barrier(0);
+      if (__builtin_expect(!(FI_PF8_KO & 32) && __any(!(fmaxf(fmaxf(cs0, cs1), fmaxf(cs2, cs3)) <= 448.f)), 0)) {
+        // rare: some probability may have left the e4m3 range -- exact maximum of tile t, move the exponent, again
+        rescale_to(fmaxf(m_run, row_max(sc) * c_exp));
+        exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
+        exp_chunk(sc[0], 8, p8w[2], p8w[3], cs1);
+        exp_chunk(sc[1], 0, p8w[4], p8w[5], cs2);
+        exp_chunk(sc[1], 8, p8w[6], p8w[7], cs3);
+      }
+      l_run += (cs0 + cs1) + (cs2 + cs3);
       const i32x8 p8 = {p8w[0], p8w[1], p8w[2], p8w[3], p8w[4], p8w[5], p8w[6], p8w[7]};
       // ---- region B ----  (the fourth QK^T MFMA runs under the wait for the first V^T fragment)
-      if constexpr (MASK) apply_mask(t + 1, sn);
       FI_F8_VWAIT(4, va);
-      o_acc[0] = FI_F8_PV(FI_F8_VFRAG(va), p8, o_acc[0]);
-      float mx = max_chunk(sn[0], 0, -INFINITY);
-      mx = max_chunk(sn[0], 8, mx);
+      { const i32x8 vf = FI_F8_VFRAG(va); FI_F8_PV(o_acc[0], vf, p8); }
       FI_F8_VREAD(va, 2)
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_VWAIT(4, vb);
-      o_acc[1] = FI_F8_PV(FI_F8_VFRAG(vb), p8, o_acc[1]);
-      mx = max_chunk(sn[1], 0, mx);
-      mx = max_chunk(sn[1], 8, mx);
+      { const i32x8 vf = FI_F8_VFRAG(vb); FI_F8_PV(o_acc[1], vf, p8); }
       FI_F8_VREAD(vb, 3)
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_VWAIT(4, va);
-      o_acc[2] = FI_F8_PV(FI_F8_VFRAG(va), p8, o_acc[2]);
-      // the decision of the deferred rescale runs under the last two MFMAs; only its (rare) application waits for them
-      float m_true;
-      const bool resc = rescale_decide(mx, t + 1 < num_tiles, m_true);
+      { const i32x8 vf = FI_F8_VFRAG(va); FI_F8_PV(o_acc[2], vf, p8); }
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_VWAIT(0, vb);
-      o_acc[3] = FI_F8_PV(FI_F8_VFRAG(vb), p8, o_acc[3]);
+      { const i32x8 vf = FI_F8_VFRAG(vb); FI_F8_PV(o_acc[3], vf, p8); }
       if (FI_PF8_KO & 8) asm volatile("" :: "v"(p8), "v"(va[0]), "v"(vb[0]));
+      if constexpr (MASK) apply_mask(t + 1, sn);
 #undef FI_F8_VREAD
 #undef FI_F8_VWAIT
 #undef FI_F8_VFRAG
-#undef FI_F8_QK
+#undef FI_F8_QK0
+#undef FI_F8_QK1
 #undef FI_F8_PV
-      __builtin_amdgcn_sched_barrier(0);
-      if (resc) rescale_apply(m_true);
-      if (!(FI_PF8_KO & 4)) {
-        asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");  // K of tile t+2 (and everything older) landed
-        __builtin_amdgcn_s_barrier();
-      }
+      // K of tile t+2 (and everything older, V of tile t+1 included) of this wave's pieces landed; then the
+      // workgroup barrier.  ONE asm statement: the s_barrier builtin alone is no memory fence for the compiler,
+      // which would hoist the next step's LDS reads between the wait and the barrier.
+      if (!(FI_PF8_KO & 4)) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     auto refill_if_needed = [&](int t_first, int t_last) {
       if (p.kv_indices && !(ids_cover(t_first + 4) && ids_cover(t_last + 4))) {  // uniform; rare
@@ -491,8 +526,9 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       if (t + 2 < num_tiles) step(integral_constant<int, 2>{}, true_type{}, s_a, s_b, t + 2);
       if (t + 3 < num_tiles) step(integral_constant<int, 3>{}, true_type{}, s_b, s_a, t + 3);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped extra tiles still land in the ring
-    __builtin_amdgcn_s_barrier();
+    // the clamped extra tiles still land in the ring; the s_nops cover the last P.V MFMAs (asm statements: the
+    // compiler does not pad their result latency) before the epilogue reads the accumulators
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
   }
 
   // ---- finalize: l_run carries the constant factor of P8, so O / l_run is free of it ----
