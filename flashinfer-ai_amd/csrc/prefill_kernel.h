@@ -167,7 +167,9 @@ __device__ __forceinline__ float round_through_e4m3(float x) {
 
 // T16: MFMA compute type; KVS: K/V storage dtype; QS: Q storage dtype; D: head_dim (64 / 128)
 // GENERAL: ALiBi / logits soft cap compiled in (kept out of the common instantiation's hot loop)
-template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL>
+// SPLIT_P: bf16 only -- P enters P.V as hi + lo bf16 halves (two MFMAs over the same V fragment, 16 mantissa
+//   bits) instead of one bf16 rounding (8 bits); see the P.V block
+template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL, bool SPLIT_P>
 // head_dim 256 keeps 128 accumulator + 64 query-fragment registers per lane: one wave per SIMD (512 registers)
 __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     batch_prefill_kernel(const PrefillKernelParams p) {
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   using frag_t = typename M::frag;
   constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
   constexpr bool Q_FP8 = (QS == FI_DTYPE_FP8_E4M3 || QS == FI_DTYPE_FP8_E5M2);
+  constexpr bool P_HI_LO = SPLIT_P && T16 == FI_DTYPE_BF16 && !Q_FP8;
   [[maybe_unused]] constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
   constexpr int ROWB = D * 2;             // bytes per row of the 16-bit LDS images
   constexpr int CPR = D / 8;              // 16-byte chunks per row
@@ -668,6 +671,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           u32x4 w;
+          [[maybe_unused]] u32x4 w_lo;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float a = s_acc[kbk][8 * s2 + 2 * j], b = s_acc[kbk][8 * s2 + 2 * j + 1];
@@ -678,6 +682,14 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
               b = back[1];
             }
             w[j] = pack2<T16>(a, b);
+            if constexpr (P_HI_LO) {
+              // A bf16 P carries 8 mantissa bits: with |o| << |v| (cancelling rows) the rounding shows as
+              // ~2^-9 |p v| absolute, 4e-3 on unit-variance V.  The residual p - bf16(p) is exact in f32 and
+              // its own bf16 rounding leaves 2^-17 relative.
+              const float a_hi = __builtin_bit_cast(float, w[j] << 16);
+              const float b_hi = __builtin_bit_cast(float, w[j] & 0xffff0000u);
+              w_lo[j] = pack2<T16>(a - a_hi, b - b_hi);
+            }
           }
           const frag_t pfrag = __builtin_bit_cast(frag_t, w);
 #pragma unroll
@@ -690,6 +702,8 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
             using s16x8 = __attribute__((ext_vector_type(8))) short;
             const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pfrag, o_acc[db]);
+            if constexpr (P_HI_LO)
+              o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, w_lo), o_acc[db]);
           }
         }
       }

@@ -98,7 +98,7 @@ def test_fuzz_batch_prefill(seed):
     variant = rng.choice(["plain", "plain", "rope", "alibi", "window", "softcap", "mask"])
     kw, okw = {}, {}
     if variant == "rope":
-        kw, okw = dict(pos_encoding_mode="ROPE_LLAMA"), dict(pos_encoding_mode="ROPE_LLAMA")
+        kw, okw = dict(pos_encoding_mode="ROPE_LLAMA"), dict(pos_encoding_mode="ROPE_LLAMA", rope_round_dtype=qdt)
     elif variant == "alibi":
         kw, okw = dict(pos_encoding_mode="ALIBI"), dict(pos_encoding_mode="ALIBI")
     elif variant == "window":
@@ -128,6 +128,8 @@ def test_fuzz_batch_prefill(seed):
                                          causal=causal, custom_mask=mask, **okw)
     t = ptol(qdt)
     if variant == "rope":
+        # the oracle rounds the rotated q / k to the 16-bit type like the kernel; what is left is the occasional
+        # element whose rounding flips with the sin / cos precision
         t = dict(rtol=t["rtol"] * 2, atol=t["atol"] * 2)
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), **t)
     # fused RoPE re-rounds the rotated q / k to the 16-bit type (as the reference does in shared memory,

@@ -12,11 +12,14 @@ DEV = "cuda:0"
 
 
 def ptol(dtype):
-    """fp16: rtol = atol = 1e-3 (the reference's bar).  bf16: the probabilities enter the P.V MFMA rounded
-    to bf16 (8-bit significand, as the reference's bf16 kernels do, prefill.cuh:962-985) and the output is
-    rounded to bf16 again, so the bar is two bf16 ulps relative / 4e-3 absolute against the exact oracle."""
+    """fp16: rtol = atol = 1e-3 (the reference's bar).  bf16: the same bar plus the rounding of the bf16 output
+    itself (half an ulp = 2^-9 relative; 2^-8 granted).  The kernel feeds P to the P.V MFMA as hi + lo bf16
+    halves, so P carries 16 mantissa bits; with the reference's single bf16 rounding of P (prefill.cuh:962-985;
+    FI_PREFILL_BF16_SINGLE_P=1 here) 83 of the 383 bf16 cases of the 900-seed fuzz sweep exceed even
+    rtol 2^-7 / atol 2e-3, all on cancelling rows (|o| << |v|: the error is ~2^-9 sum |p v|; worst 4.6e-3 at
+    seed 637, request 1, row 544, head 16 -- tools/bf16_error_scan.py prints the census)."""
     if dtype == torch.bfloat16:
-        return dict(rtol=2.0 ** -6, atol=4e-3)
+        return dict(rtol=1e-3 + 2.0 ** -8, atol=1e-3)
     return dict(rtol=1e-3, atol=1e-3)
 
 
@@ -81,9 +84,12 @@ def test_single_prefill_variants(kw):
     k, v = torch.randn(kv_len, hkv, d).half(), torch.randn(kv_len, hkv, d).half()
     o, lse = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), causal=True,
                                                      return_lse=True, **kw)
-    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), causal=True, **kw)
-    # fused RoPE rounds the rotated q/k to fp16 before QK^T as the reference does (prefill.cuh:465-612)
-    t = 3e-3 if kw.get("pos_encoding_mode") == "ROPE_LLAMA" else 1e-3
+    # fused RoPE rounds the rotated q/k to fp16 before QK^T as the reference does (prefill.cuh:465-612); the
+    # oracle models that rounding, the kernel's sin / cos may still flip the rounding of single elements
+    rope = kw.get("pos_encoding_mode") == "ROPE_LLAMA"
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), causal=True,
+                                     rope_round_dtype=torch.float16 if rope else None, **kw)
+    t = 2e-3 if rope else 1e-3
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=t, atol=t)
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=t, atol=5 * t)
 
@@ -359,7 +365,8 @@ def test_prefill_head_dim_256(dtype, causal):
     qs = torch.randn(200, hq, d).to(dtype)
     os_, lses = flashinfer.single_prefill_with_kv_cache(qs.to(DEV), k.to(DEV), v.to(DEV), causal=causal,
                                                         pos_encoding_mode="ROPE_LLAMA", return_lse=True)
-    os_ref, lses_ref = R.attention_ref(qs.float(), k.float(), v.float(), causal=causal, pos_encoding_mode="ROPE_LLAMA")
+    os_ref, lses_ref = R.attention_ref(qs.float(), k.float(), v.float(), causal=causal, pos_encoding_mode="ROPE_LLAMA",
+                                       rope_round_dtype=dtype)
     torch.testing.assert_close(os_.float().cpu(), os_ref.float(), **ptol(dtype))
     torch.testing.assert_close(lses.cpu(), lses_ref.float(), rtol=2e-3, atol=2e-3)
 
