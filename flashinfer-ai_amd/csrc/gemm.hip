@@ -18,66 +18,9 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace fi {
-
-constexpr int kGemmThreads = 256;
-constexpr int kBM = 128, kBN = 128, kBK = 128;
-
-struct GemmParams {
-  const uint8_t* a;
-  const uint8_t* b;
-  const float* a_scale;
-  const float* b_scale;
-  void* d;
-  const int32_t* m_indptr;  // [G+1] device; NULL: one group of m_total rows
-  int32_t num_groups, m_total, n, k;
-  int32_t a_gran_m;         // 1 or 128
-  int32_t scale_k_major;    // 0: "MN" major, 1: "K" major
-  int32_t out_dtype;
-  int32_t num_m_tiles_bound;  // grid bound on (group, m tile) pairs
-  int32_t num_m_tiles_bound_ws;  // the same for the 256-row tiles of the producer/consumer kernel
-  int32_t n_tiles;
-  int32_t a_is_e5m2, b_is_e5m2;
-};
-
-using f32x16g = __attribute__((ext_vector_type(16))) float;
-
-// (group, m tile) of the mt_global-th m tile from the running count of tiles per group, on the device (the
-// reference's arg-prep kernel group_gemm_fp8_groupwise_sm100.cuh:35-72 also sizes the groups on the device, no
-// host sync).  Wave-parallel: 64 groups per pass -- lane i loads m_indptr[i], [i + 1], an inclusive scan over
-// the lanes gives each group's first tile -- so that 256 experts cost 4 passes, not 256 dependent loads.
-// Every lane of every wave runs it with the same arguments and gets the same (uniform) answer.
-template <int TILE_M>
-__device__ __forceinline__ bool find_group_tile(const int32_t* m_indptr, int num_groups, int mt_global, int lane,
-                                                int& g, int& m_begin, int& m_end, int& mt) {
-  int first = 0;  // tiles in the groups of earlier passes
-  for (int base = 0; base < num_groups; base += 64) {
-    const int gi = base + lane;
-    const bool in = gi < num_groups;
-    const int lo = in ? m_indptr[gi] : 0, hi = in ? m_indptr[gi + 1] : 0;
-    const int tiles = (hi - lo + TILE_M - 1) / TILE_M;
-    int incl = tiles;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int v = __shfl_up(incl, d, 64);
-      if (lane >= d) incl += v;
-    }
-    const int start = first + incl - tiles;
-    const uint64_t hit = __ballot(in && mt_global >= start && mt_global < start + tiles);
-    if (hit) {
-      const int src = __builtin_ctzll(hit);
-      g = base + src;
-      m_begin = __builtin_amdgcn_readlane(lo, src);
-      m_end = __builtin_amdgcn_readlane(hi, src);
-      mt = mt_global - __builtin_amdgcn_readlane(start, src);
-      return true;
-    }
-    first += __builtin_amdgcn_readlane(incl, 63);
-  }
-  return false;
-}
 
 template <bool A_E5M2, bool B_E5M2>
 __device__ __forceinline__ f32x16g mfma_fp8(long a, long b, f32x16g c) {
@@ -88,7 +31,6 @@ __device__ __forceinline__ f32x16g mfma_fp8(long a, long b, f32x16g c) {
 }
 
 // MA_E5M2 / MB_E5M2 refer to the MFMA A operand (= matrix B of the GEMM) and MFMA B operand (= matrix A)
-using i32x8g = __attribute__((ext_vector_type(8))) int;
 
 // MX: use the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 with unit (E8M0 = 127) scales -- the plain fp8
 // product at twice the rate of the non-scaled fp8 MFMA (MI355X_MICROARCH.md, matrix cores).
@@ -978,6 +920,19 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
       default: group_gemm_fp8_dma_kernel<true, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
     }
     return hipGetLastError();
+  }
+  // 256 x 256 tiles (gemm_big.hip) once every CU gets a few of them; FI_GEMM_BIG=0 keeps 256 x 128
+  static const int big_min_tiles = [] {
+    const char* e = getenv("FI_GEMM_BIG");
+    if (e && atoi(e) == 0) return -1;
+    const char* t = getenv("FI_GEMM_BIG_MIN_TILES");
+    return t ? atoi(t) : 4 * fi_num_compute_units();
+  }();
+  if (use_ws && use_dma && big_min_tiles >= 0 && !tall &&
+      p.num_m_tiles_bound_ws * ceil_div(p.n, 2 * kBN) >= big_min_tiles) {
+    GemmParams q = p;
+    q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
+    return launch_gemm_big(q, ws_grid, stream);
   }
   if (use_ws && use_dma) {
     GemmParams q = p;

@@ -2,6 +2,7 @@
 
 The library picks the kernel by problem size (256 x 128 persistent kernels from 2 x CUs tiles on) and reads its
 switches once per process, so the forced variants run in a child process:
+  FI_GEMM_WS_MIN_TILES=0 FI_GEMM_BIG_MIN_TILES=0 -> every shape takes the 256 x 256 kernel (gemm_big.hip)
   FI_GEMM_WS_MIN_TILES=0 FI_GEMM_DMA_TM=256 / 128 -> every shape takes the persistent LDS-DMA kernel with
                                        256 x 128 / 128 x 256 tiles
   FI_GEMM_WS_MIN_TILES=0 FI_GEMM_DMA=0 -> ... the persistent register-staged kernel
@@ -16,10 +17,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("env", [{"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA_TM": "256"},
+@pytest.mark.parametrize("env", [{"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_BIG_MIN_TILES": "0"},
+                                 {"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA_TM": "256", "FI_GEMM_BIG": "0"},
                                  {"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA_TM": "128"},
                                  {"FI_GEMM_WS_MIN_TILES": "0", "FI_GEMM_DMA": "0"}],
-                         ids=["dma-256x128", "dma-128x256", "register-staged"])
+                         ids=["dma-256x256", "dma-256x128", "dma-128x256", "register-staged"])
 def test_gemm_suite_through_forced_kernel(env):
     child_env = dict(os.environ)
     child_env.update(env)
