@@ -65,11 +65,28 @@ static int pick_head_tile(int group_size, int kv_dt = FI_DTYPE_BF16) {
 
 // Matrix-core decode (decode_mfma_kernel.h): groups too wide for the VALU kernel, K/V stored in the q
 // dtype.  FI_DECODE_MFMA_MIN_GROUP moves the crossover (0 disables the path).
-hipError_t decode_mfma_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int grid,
+hipError_t decode_mfma_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int rope, int grid,
                               hipStream_t stream);
+hipError_t decode_mfma16_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int rope,
+                                int grid, hipStream_t stream);
+// the 16x16x32 form (decode_mfma16_kernel.h) serves every group of <= 16 heads the matrix-core path accepts:
+// measured >= the VALU kernel (G <= 4) and >= the 32x32x16 form (G 5..16) on every shape of
+// tools/bench_decode_kernels.py (C2 6.35 -> 6.52 TB/s, bs 8 x 1024 20.3 -> 16.1 us), and the only one with room
+// for the fused-RoPE rotation.  FI_DECODE_MFMA16=0 restores the r1 choice.
+static bool mfma16_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("FI_DECODE_MFMA16");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return on;
+}
+static bool mfma16_decode(int group_size, bool rope) {
+  (void)rope;
+  return group_size <= 16 && mfma16_enabled();
+}
 static int tokens_per_load(int kv_dt, int head_dim);
 static int ilog2_exact(int x);
-static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim, int page_size) {
+static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim, int page_size, bool rope = false) {
   static const int min_group = [] {
     const char* e = getenv("FI_DECODE_MFMA_MIN_GROUP");
     return e ? atoi(e) : 5;
@@ -86,6 +103,14 @@ static bool mfma_decode_shape(int group_size, int q_dt, int kv_dt, int head_dim,
   // page-lookup fallback runs at 4.5 TB/s (page_size 1), the matrix-core kernel -- which always gathers per
   // lane -- at 6.3; token-granular page tables (page_size 1) are common
   if (mg > 0 && (ilog2_exact(page_size) < 0 || page_size < tokens_per_load(kv_dt, head_dim))) mg = 1;
+  // fused RoPE: the K rotation is vector-ALU work that the VALU kernel has no room for (4.8 TB/s at G = 4);
+  // on the matrix-core kernel it rides an idle pipe.  FI_DECODE_MFMA_ROPE=0 keeps the VALU kernel.
+  static const bool rope_on_mfma = [] {
+    const char* e = getenv("FI_DECODE_MFMA_ROPE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (rope && mg > 0) mg = rope_on_mfma ? 1 : 0x7fffffff;
+  if (!rope && mg > 0 && group_size <= 16 && mfma16_enabled()) mg = 1;
   return mg > 0 && group_size >= mg && (q_dt == kv_dt || fp8) &&
          (q_dt == FI_DTYPE_F16 || q_dt == FI_DTYPE_BF16) && (head_dim == 64 || head_dim == 128);
 }
@@ -349,8 +374,9 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   kp.kv_stride_page = kv.stride_page;
   kp.kv_stride_n = kv.stride_n;
   kp.kv_stride_h = kv.stride_h;
-  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim, kv.page_size) &&
-                        a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
+  const bool rope = a->pos_encoding_mode == FI_POS_ROPE_LLAMA;
+  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim, kv.page_size, rope) &&
+                        a->pos_encoding_mode != FI_POS_ALIBI && !(a->logits_soft_cap > 0.f) &&
                         kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
   if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   kp.num_items = (int32_t)(padded * kv.num_kv_heads * kp.head_tiles);
@@ -382,8 +408,10 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
                  !getenv("FI_DECODE_FORCE_GENERIC");
   if (kp.num_items > 0) {
     const int grid = ceil_div(kp.num_items, kDecodeWaves);
-    if (use_mfma)
-      FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, kv.dtype, kv.head_dim, grid, stream));
+    if (use_mfma && mfma16_decode(kp.group_size, rope))
+      FI_HIP_CALL(decode_mfma16_launch(kp, a->q_dtype, kv.dtype, kv.head_dim, rope, grid, stream));
+    else if (use_mfma)
+      FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, kv.dtype, kv.head_dim, rope, grid, stream));
     else
       FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
   }
@@ -443,8 +471,9 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
 
-  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim, vpage) &&
-                        a->pos_encoding_mode == FI_POS_NONE && !(a->logits_soft_cap > 0.f) &&
+  const bool rope = a->pos_encoding_mode == FI_POS_ROPE_LLAMA;
+  const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim, vpage, rope) &&
+                        a->pos_encoding_mode != FI_POS_ALIBI && !(a->logits_soft_cap > 0.f) &&
                         kp.kv_stride_page < (1ll << 31);
   if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   // split-KV so that the chip is filled (ref: decode.cuh:689-733, kv_len > 256 -> chunks >= 256)
@@ -472,8 +501,10 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
     kp.tmp_lse = (float*)((char*)tmp + vbytes);
   }
   const int grid = ceil_div(kp.num_items, kDecodeWaves);
-  if (use_mfma)
-    FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, a->kv_dtype, a->head_dim, grid, stream));
+  if (use_mfma && mfma16_decode(kp.group_size, rope))
+    FI_HIP_CALL(decode_mfma16_launch(kp, a->q_dtype, a->kv_dtype, a->head_dim, rope, grid, stream));
+  else if (use_mfma)
+    FI_HIP_CALL(decode_mfma_launch(kp, a->q_dtype, a->kv_dtype, a->head_dim, rope, grid, stream));
   else
     FI_HIP_CALL(fn(kp, gt, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, grid, stream));
   if (kp.split_kv) {

@@ -1,49 +1,85 @@
-// Batch paged-KV decode on the matrix cores, for wide GQA groups (the reference's "tensor core" decode,
-// flashinfer/decode.py:1025-1063, which runs the prefill kernel with qo_len = 1).
+// Batch paged-KV decode on the matrix cores for GQA groups of up to 16 query heads: the 16x16x32 form of
+// decode_mfma_kernel.h (same work list, same wave-private K | V LDS tiles of 32 tokens, no workgroup barrier).
 //
-// The VALU decode kernel (decode_kernel.h) spends ~2 G flops of vector ALU per KV byte; above G = 4 it is
-// VALU-bound (measured 4.4 TB/s at G = 8).  Here one WAVE still owns one (request kv-chunk, kv head) item of
-// the same work list, but the G query heads become the columns of a 32x32x16 MFMA:
-//   S^T[32 kv][G..32] = K Q^T,   O^T[D][G..32] += V^T P^T
-// K/V tiles of 32 tokens are gathered with coalesced 16-byte loads into registers one tile ahead, written
-// to a wave-private LDS region (no workgroup barrier anywhere: LDS operations of one wave execute in
-// order), and read back as MFMA fragments (K: swizzled ds_read_b128, V^T: ds_read_b64_tr_b16) exactly as in
-// prefill_kernel.h.  Vector ALU work drops to the softmax of a 32 x 32 tile per 16 KB of KV, so the kernel
-// is HBM-bound for any group size up to 32.
+//   S^T[16 kv][16 heads] = K Q^T  (two 16-row halves of the tile),   O^T[16 d][16 heads] += V^T P^T (k = 32 kv)
+//
+// Against the 32x32x16 form a wave keeps 32 instead of 64 accumulator registers, 16 instead of 32 for Q and 8
+// instead of 16 for the logits, which is what lets the fused-RoPE variant (ROPE: cos / sin state + rotation
+// temporaries) stay under 256 registers, i.e. two workgroups per CU -- the 32x32 form needs ~370 for it and the
+// VALU kernel is vector-ALU bound (4.8 TB/s) with the rotation.
+//
+// Layouts (g = lane >> 4, c = lane & 15):
+//   QK^T  A = K: lane holds K[16 t + c][32 ks + 8 g .. + 8]  (ds_read_b128, chunk-swizzled rows)
+//         B = Q: lane holds Q[head c][32 ks + 8 g .. + 8]     (registers for the whole kernel)
+//         C    : s[t][j] = S[kv 16 t + 4 g + j][head c]
+//   P.V   B = P: element 4 t + j of the lane = p[t][j]        (k index 8 g + 4 t + j <-> kv row 16 t + 4 g + j)
+//         A = V^T: lane holds V[those 8 rows][16 db + c]      (two ds_read_b64_tr_b16: rows 4 g.., 16 + 4 g..)
+//         C    : o[db][j] = O[head c][16 db + 4 g + j]
+// ROPE (pos_encoding_mode = ROPE_LLAMA; ref: decode.cuh:445-466, and the reference's tensor-core decode = its
+// prefill kernel, prefill.cuh:465-612): q rotated once, every K row while it is staged into LDS; both rounded to
+// T16 for the MFMA as that path rounds them in shared memory.
 #pragma once
 #include "decode_kernel.h"
 #include "prefill_kernel.h"
 
 namespace fi {
 
-constexpr int kDmTileKV = 32;
+template <int T16>
+struct Mfma16;
+template <>
+struct Mfma16<FI_DTYPE_F16> {
+  static __device__ __forceinline__ f32x4 mfma(MfmaType<FI_DTYPE_F16>::frag a, MfmaType<FI_DTYPE_F16>::frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Mfma16<FI_DTYPE_BF16> {
+  static __device__ __forceinline__ f32x4 mfma(MfmaType<FI_DTYPE_BF16>::frag a, MfmaType<FI_DTYPE_BF16>::frag b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+  }
+};
 
-// T16: q/o (and MFMA) dtype; KVS: storage dtype of the cache (T16, or fp8 upcast to T16 while staging, as
-// the reference's decode does with an fp8 cache); PAGED: page table present (false: identity pages).
-// ROPE: pos_encoding_mode = ROPE_LLAMA fused in (ref: decode.cuh:445-466 / the reference's tensor-core decode =
-// its prefill kernel, prefill.cuh:465-612): q is rotated once, every K row while it is staged into LDS; both
-// are rounded to T16 for the MFMA, as that reference path rounds them in shared memory.  The rotation is
-// vector-ALU work in a kernel whose vector pipe is otherwise idle; the VALU decode kernel, already VALU-bound
-// at G = 4, drops to 4.8 TB/s with it.
-// (head_dim 128 with ROPE needs ~300 registers: that instantiation runs one workgroup per CU)
-template <int T16, int KVS, int D, bool PAGED, bool ROPE = false>
-__global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) decode_mfma_kernel(const DecodeKernelParams p) {
+// max / sum over the four 16-lane rows of a wave (v_permlane16_swap + v_permlane32_swap; VALU, no LDS).
+// The results are copied to scalars before the bit_cast: __builtin_bit_cast of a vector-element lvalue reads
+// element 0 with this compiler (hipcc, ROCm 7.2).
+template <bool MAX>
+__device__ __forceinline__ float reduce_rows(float x) {
+  const uint32_t u = __builtin_bit_cast(uint32_t, x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // {rows 0 0 2 2}, {rows 1 1 3 3}
+  const uint32_t r0 = r[0], r1 = r[1];
+  const float a = __builtin_bit_cast(float, r0), b = __builtin_bit_cast(float, r1);
+  const float y = MAX ? fmaxf(a, b) : a + b;
+  const uint32_t v = __builtin_bit_cast(uint32_t, y);
+  const auto q = __builtin_amdgcn_permlane32_swap(v, v, false, false);  // {lo lo}, {hi hi}
+  const uint32_t q0 = q[0], q1 = q[1];
+  const float c = __builtin_bit_cast(float, q0), d = __builtin_bit_cast(float, q1);
+  return MAX ? fmaxf(c, d) : c + d;
+}
+
+// (an fp8 cache with ROPE at head_dim 128 stages 16 dims per lane -- twice the rotation state -- and does not fit
+// 256 registers: that instantiation runs one workgroup per CU)
+template <int T16, int KVS, int D, bool PAGED, bool ROPE>
+__global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128 && KVS != T16) ? 1 : 2)
+    decode_mfma16_kernel(const DecodeKernelParams p) {
   using M = MfmaType<T16>;
   using frag_t = typename M::frag;
+  constexpr int kTile = 32;
   constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
   constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
-  constexpr int ROWB = D * 2;           // bytes per row of the (16-bit) LDS images
-  constexpr int CPR = D / 8;            // 16-byte chunks per LDS row
+  constexpr int ROWB = D * 2;             // bytes per row of the (16-bit) LDS images
+  constexpr int CPR = D / 8;              // 16-byte chunks per LDS row
   constexpr int GCH = D * KV_BYTES / 16;  // 16-byte chunks per row in the cache
-  constexpr int RPP = 64 / GCH;         // rows staged per pass by one wave
-  constexpr int NPASS = kDmTileKV / RPP;
-  constexpr int KSTEPS = D / 16;
-  constexpr int DBLK = D / 32;
-  constexpr int TILE_BYTES = kDmTileKV * ROWB;
+  constexpr int RPP = 64 / GCH;           // rows staged per pass by one wave
+  constexpr int NPASS = kTile / RPP;
+  constexpr int KSTEPS = D / 32;
+  constexpr int DBLK = D / 16;
+  constexpr int TILE_BYTES = kTile * ROWB;
+  constexpr int NE = KV_FP8 ? 16 : 8;     // dims one lane stages per pass
+  static_assert(D == 64 || D == 128, "head_dim 64 / 128");
 
   __shared__ __attribute__((aligned(16))) char smem[kDecodeWaves][2 * TILE_BYTES];  // per wave: K | V
-  // fused RoPE: cos / sin of (rows per pass) x freq for the NE dims of every staging chunk, shared by the waves
-  __shared__ __attribute__((aligned(16))) float rope_step[ROPE ? (D * (KV_FP8 ? 1 : 2) / 16) * (KV_FP8 ? 16 : 8) * 2 : 4];
+  // fused RoPE: cos / signed sin of (rows per pass) x freq for the NE dims of every staging chunk
+  __shared__ __attribute__((aligned(16))) float rope_step[ROPE ? GCH * NE * 2 : 4];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -58,13 +94,11 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
   if (item >= p.num_items) return;
   char* const kb = smem[wave];
   char* const vb = kb + TILE_BYTES;
-  const int lq = lane & 31, lh = lane >> 5;
+  const int lc = lane & 15, lg = lane >> 4;
 
-  // ---- item -> (work, kv head, 32-head column block); the work list is the VALU kernel's, with one
-  // head tile per 32 query heads of the group (one tile for every group up to 32) ----
-  const int col_blk = item % p.head_tiles;
-  const int kv_head = (item / p.head_tiles) % p.num_kv_heads;
-  const int work = item / (p.head_tiles * p.num_kv_heads);
+  // ---- item -> (work, kv head); one head tile: the whole group (<= 16 heads) is this wave's 16 columns ----
+  const int kv_head = item % p.num_kv_heads;
+  const int work = item / p.num_kv_heads;
   int req = 0, kv_tile = work;
   if (p.request_indices) {
     if (p.block_valid_mask && !p.block_valid_mask[work]) return;
@@ -79,9 +113,7 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
   } else {
     kv_len = p.single_kv_len;
   }
-  // sliding window (ref: variants.cuh:78-91 with qo_len = 1): visible iff kv_idx >= kv_len - 1 - window_left.
-  // With a planned window the chunks start at the first page that can intersect it (decode.hip); inside its
-  // chunk the wave starts at the 32-token tile that holds the window start.
+  // sliding window / planned window / chunk bounds: as in decode_mfma_kernel.h
   int chunk_base = 0;
   if (p.plan_window_left >= 0 && p.indptr) {
     const int np = p.indptr[req + 1] - page_begin;
@@ -91,18 +123,18 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
   const int kv_chunk_size = p.kv_chunk_size_ptr ? *p.kv_chunk_size_ptr : p.kv_chunk_size;
   int chunk_start = chunk_base + (p.split_kv ? kv_tile * kv_chunk_size : 0);
   const int chunk_end = p.split_kv ? min(chunk_start + kv_chunk_size, kv_len) : kv_len;
-  if (win_start > chunk_start) chunk_start += (win_start - chunk_start) / kDmTileKV * kDmTileKV;
-  const int G = min(p.group_size - 32 * col_blk, 32);  // heads of this column block
-  const int head0 = kv_head * p.group_size + 32 * col_blk;
-  const int head = head0 + min(lq, G - 1);
+  if (win_start > chunk_start) chunk_start += (win_start - chunk_start) / kTile * kTile;
+  const int G = p.group_size;  // <= 16 (checked on the host)
+  const int head0 = kv_head * G;
+  const int head = head0 + min(lc, G - 1);
 
-  // ---- Q fragments: lane (q = head column, h) holds Q[head][16 ks + 8 h + 0..7] ----
+  // ---- Q fragments ----
   frag_t qf[KSTEPS];
   {
     const uint16_t* qrow = (const uint16_t*)p.q + (int64_t)req * p.q_stride_n + (int64_t)head * p.q_stride_h;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks)
-      qf[ks] = __builtin_bit_cast(frag_t, *(const u32x4*)(qrow + 16 * ks + 8 * lh));
+      qf[ks] = __builtin_bit_cast(frag_t, *(const u32x4*)(qrow + 32 * ks + 8 * lg));
     if constexpr (ROPE) {
       // dims i and i + D/2 pair up: k-steps ks and ks + KSTEPS/2 of the same lane; q sits at kv_len - 1 unless
       // the caller passed its position
@@ -117,7 +149,7 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
           float ra[2], rb[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const int i = 16 * ks + 8 * lh + 2 * w + e;  // < D/2
+            const int i = 32 * ks + 8 * lg + 2 * w + e;  // < D/2
             const float freq = p.rope_rcp_scale * __powf(p.rope_rcp_theta, (float)(2 * i) / (float)D);
             float sn, cs;
             sincos_ool((float)q_pos * freq, &sn, &cs);
@@ -136,7 +168,7 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
   }
   const float c_log2 = p.sm_scale * kLog2e;
 
-  // ---- staging: pass ps covers rows ps*RPP + lane/CPR, chunk lane%CPR ----
+  // ---- staging: pass ps covers rows ps * RPP + lane / GCH, cache chunk lane % GCH ----
   const int st_row = lane / GCH, st_ch = lane % GCH;
   const int64_t thread_off = (int64_t)kv_head * p.kv_stride_h + st_ch * (16 / KV_BYTES);
   const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
@@ -161,19 +193,20 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
       st.v[ps] = __builtin_nontemporal_load((const u32x4*)((const char*)p.v + off * KV_BYTES));
     }
   };
+  // K image: 16-byte chunks XOR-swizzled so that the 16 rows one ds_read_b128 lane group touches spread over
+  // the banks.  V image: 32-byte slots (= one 16-column d block) swizzled per row for ds_read_b64_tr_b16, whose
+  // 32-lane halves read 8 rows x 32 bytes.
   auto k_lds_off = [&](int row, int ch) -> int {
     const int sw = (CPR >= 16) ? (row & 15) : ((row >> 1) & 7);
     return row * ROWB + ((ch ^ sw) << 4);
   };
-  auto v_lds_off = [&](int row, int ch) -> int {
-    const int f = (ROWB >= 256) ? (row & 3) : ((row >> 1) & 1);
-    return row * ROWB + (((ch >> 2) ^ f) << 6) + ((ch & 3) << 4);
+  auto v_slot_key = [&](int row) -> int { return (ROWB >= 256) ? (row & 7) : ((row >> 1) & 3); };
+  auto v_lds_off = [&](int row, int ch) -> int {  // ch: 16-byte chunk of the row
+    return row * ROWB + (((ch >> 1) ^ v_slot_key(row)) << 5) + ((ch & 1) << 4);
   };
-  // fused RoPE on K: this lane always stages the same NE dims (8, or 16 with an fp8 cache) of rows RPP apart, so
-  // cos / sin of its angles advance by a fixed rotation per pass (angle-addition recurrence, 4 FMAs per dim)
-  // and are re-seeded with the hardware sin / cos every 4 tiles.  The partner dim (i +- D/2) is GCH/2 lanes
-  // away in the same row; the sign of the sine term is folded into the state.
-  constexpr int NE = KV_FP8 ? 16 : 8;
+
+  // ---- fused RoPE on K (see decode_mfma_kernel.h): per-lane cos / sin recurrence over the passes, re-seeded
+  // every 4 tiles; the per-pass rotation lives in LDS, the sign of the sine term is folded into the state ----
   [[maybe_unused]] float rc[ROPE ? NE : 1], rs[ROPE ? NE : 1];
   [[maybe_unused]] const int rope_pos0 = ROPE && p.kv_rope_pos_offset ? p.kv_rope_pos_offset[req] : 0;
   [[maybe_unused]] auto rope_freq = [&](int e) {
@@ -182,8 +215,7 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
   };
   [[maybe_unused]] const float rope_sgn = (st_ch < GCH / 2) ? -1.f : 1.f;
   if constexpr (ROPE) {
-    // every wave writes the same values (no workgroup barrier needed: a wave reads what it wrote itself, and
-    // waves that return early above never reach a barrier)
+    // every wave writes the same values: no workgroup barrier (waves that returned above never reach one)
     if (st_row == 0) {
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
@@ -224,12 +256,9 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
     }
     return outw;
   };
-  // the per-pass rotation (cos, signed sin of RPP x freq) depends on the chunk only: it lives in LDS and is read
-  // back every pass (kept in registers it costs 2 NE more of them, and the D = 128 kernel has none to spare);
-  // the address passes through an empty asm so that the reads stay inside the loop
   [[maybe_unused]] uint32_t step_off = (uint32_t)(st_ch * NE * 2) * 4u;
   [[maybe_unused]] auto rope_advance = [&]() {
-    asm volatile("" : "+v"(step_off));
+    asm volatile("" : "+v"(step_off));  // keeps the table reads inside the loop (2 NE registers otherwise)
     const float* const tab = (const float*)((const char*)rope_step + step_off);
 #pragma unroll
     for (int e4 = 0; e4 < NE; e4 += 4) {
@@ -268,150 +297,137 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128) ? 1 : 2) de
         *(u32x4*)(kb + k_lds_off(row, st_ch)) = k0;
         *(u32x4*)(vb + v_lds_off(row, st_ch)) = st.v[ps];
       }
-      // one pass at a time: left alone the scheduler overlaps the rotations of all passes and spills
-      if constexpr (ROPE) __builtin_amdgcn_sched_barrier(0);
+      if constexpr (ROPE) __builtin_amdgcn_sched_barrier(0);  // one pass at a time (register pressure)
     }
   };
+  // fragment read addresses
   int k_rd[KSTEPS];
 #pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = k_lds_off(lq, 2 * ks + lh);
-  const int q4 = (lane & 15) >> 2, p4 = lane & 3, gpar = (lane >> 4) & 1;
+  for (int ks = 0; ks < KSTEPS; ++ks) k_rd[ks] = k_lds_off(lc, 4 * ks + lg);
+  // V^T: the 16 lanes of row group g present rows 4 g + q4, 8-byte pieces p4 of a 32-byte d block
+  const int q4 = lc >> 2, p4 = lc & 3;
+  const int v_row = 4 * lg + q4;  // second read: + 16 rows (same swizzle key)
   int v_rd[DBLK];
 #pragma unroll
-  for (int db = 0; db < DBLK; ++db) {
-    const int row = 4 * lh + q4;
-    const int col_byte = (32 * db + 16 * gpar + 4 * p4) * 2;
-    const int f = (ROWB >= 256) ? (row & 3) : ((row >> 1) & 1);
-    v_rd[db] = row * ROWB + (((col_byte >> 6) ^ f) << 6) + (col_byte & 63);
-  }
+  for (int db = 0; db < DBLK; ++db) v_rd[db] = v_row * ROWB + ((db ^ v_slot_key(v_row)) << 5) + p4 * 8;
 
-  f32x16 o_acc[DBLK];
+  f32x4 o_acc[DBLK];
 #pragma unroll
-  for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
+  for (int db = 0; db < DBLK; ++db) o_acc[db] = f32x4{0.f, 0.f, 0.f, 0.f};
   float m_run = -1.0e30f, l_run = 0.f;
 
   const int n_tok = chunk_end - chunk_start;
   if (n_tok > 0) {
-    const int ntiles = (n_tok + kDmTileKV - 1) / kDmTileKV;
+    const int ntiles = (n_tok + kTile - 1) / kTile;
     int pg[NPASS], en[NPASS];
     Stage st;
     fetch_pages(chunk_start, pg, en);
     issue_loads(pg, en, st);
-    fetch_pages(chunk_start + kDmTileKV, pg, en);
+    fetch_pages(chunk_start + kTile, pg, en);
     for (int t = 0; t < ntiles; ++t) {
-      const int tile0 = chunk_start + t * kDmTileKV;
+      const int tile0 = chunk_start + t * kTile;
       if constexpr (ROPE)
         if ((t & 3) == 0) rope_seed(rope_pos0 + tile0 + st_row);
       write_stage(st);  // waits for the tile's loads
       __builtin_amdgcn_wave_barrier();
       if (t + 1 < ntiles) {
-        issue_loads(pg, en, st);  // tile t+1 streams in while tile t is consumed
-        fetch_pages(tile0 + 2 * kDmTileKV, pg, en);
+        issue_loads(pg, en, st);  // tile t + 1 streams in while tile t is consumed
+        fetch_pages(tile0 + 2 * kTile, pg, en);
       }
       // ---- S^T = K Q^T ----
-      f32x16 s_acc;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s_acc[r] = 0.f;
+      f32x4 s_acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
-        const u32x4 a = *(const u32x4*)(kb + k_rd[ks]);
-        s_acc = M::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc);
-      }
-      if (tile0 + kDmTileKV > chunk_end || tile0 < win_start) {
-        // tail tile / window-start tile: accumulator register r of lane (q, lh) is kv row
-        // 8 (r >> 2) + 4 lh + (r & 3); visible rows are [win_start, chunk_end)
-        const int lo = win_start - tile0 - 4 * lh, hi = chunk_end - tile0 - 4 * lh;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2);
-          s_acc[r] = (row >= lo && row < hi) ? s_acc[r] : -INFINITY;
+        for (int h = 0; h < 2; ++h) {
+          const u32x4 a = *(const u32x4*)(kb + k_rd[ks] + h * 16 * ROWB);
+          s_acc[h] = Mfma16<T16>::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc[h]);
         }
       }
-      // ---- online softmax (base 2) ----
-      float mx = s_acc[0];
+      if (tile0 + kTile > chunk_end || tile0 < win_start) {
+        // register j of half h is kv row 16 h + 4 g + j; visible rows are [win_start, chunk_end)
+        const int lo = win_start - tile0 - 4 * lg, hi = chunk_end - tile0 - 4 * lg;
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s_acc[r]);
-      mx = fmaxf(mx, swap_halves(mx));
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int row = 16 * h + j;
+            s_acc[h][j] = (row >= lo && row < hi) ? s_acc[h][j] : -INFINITY;
+          }
+      }
+      // ---- online softmax (base 2) ----
+      float mx = fmaxf(fmaxf(fmaxf(s_acc[0][0], s_acc[0][1]), fmaxf(s_acc[0][2], s_acc[0][3])),
+                       fmaxf(fmaxf(s_acc[1][0], s_acc[1][1]), fmaxf(s_acc[1][2], s_acc[1][3])));
+      mx = reduce_rows<true>(mx);
       const float m_new = fmaxf(m_run, mx * c_log2);
       const float alpha = fast_exp2(m_run - m_new);
       m_run = m_new;
       float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s_acc[r] = fast_exp2(__builtin_fmaf(s_acc[r], c_log2, -m_new));
-        psum += s_acc[r];
-      }
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s_acc[h][j] = fast_exp2(__builtin_fmaf(s_acc[h][j], c_log2, -m_new));
+          psum += s_acc[h][j];
+        }
       l_run = l_run * alpha + psum;
       if (__any(alpha != 1.0f)) {
 #pragma unroll
-        for (int db = 0; db < DBLK; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[db][r] *= alpha;
+        for (int db = 0; db < DBLK; ++db) o_acc[db] *= alpha;
       }
-      // ---- O^T += V^T P^T (accumulator registers 8s..8s+7 are the B operand of k-step s) ----
-      // The VALU decode kernel (and the reference's CUDA-core decode, decode.cuh:131-144) accumulates p * v
-      // with p in f32.  A bf16 P would lose 8 of its bits, so with bf16 the probabilities go through the
-      // matrix pipe as hi + lo = bf16(p) + bf16(p - bf16(p)) (two MFMAs; the pipe is idle most of the time
-      // in this HBM-bound kernel) and the result does not depend on which decode kernel was selected.
+      // ---- O^T += V^T P^T; with bf16 the probabilities go through as hi + lo (see decode_mfma_kernel.h) ----
+      u32x4 w, wl;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        u32x4 w, wl;
+      for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float a = s_acc[8 * s2 + 2 * j], b = s_acc[8 * s2 + 2 * j + 1];
-          w[j] = pack2<T16>(a, b);
+        for (int j2 = 0; j2 < 2; ++j2) {
+          const float a = s_acc[h][2 * j2], b = s_acc[h][2 * j2 + 1];
+          const uint32_t pk = pack2<T16>(a, b);
+          w[2 * h + j2] = pk;
           if constexpr (T16 == FI_DTYPE_BF16) {
-            const float ha = __builtin_bit_cast(float, w[j] << 16);
-            const float hb = __builtin_bit_cast(float, w[j] & 0xffff0000u);
-            wl[j] = pack2<T16>(a - ha, b - hb);
+            const float ha = __builtin_bit_cast(float, pk << 16);
+            const float hb = __builtin_bit_cast(float, pk & 0xffff0000u);
+            wl[2 * h + j2] = pack2<T16>(a - ha, b - hb);
           }
         }
-        const frag_t pfrag = __builtin_bit_cast(frag_t, w);
+      const frag_t pfrag = __builtin_bit_cast(frag_t, w);
 #pragma unroll
-        for (int db = 0; db < DBLK; ++db) {
-          const char* base = vb + (16 * s2) * ROWB + v_rd[db];
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(base + 8 * ROWB));
-          using s16x8 = __attribute__((ext_vector_type(8))) short;
-          const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pfrag, o_acc[db]);
-          if constexpr (T16 == FI_DTYPE_BF16)
-            o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, wl), o_acc[db]);
-        }
+      for (int db = 0; db < DBLK; ++db) {
+        const char* base = vb + v_rd[db];
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(base + 16 * ROWB));
+        using s16x8 = __attribute__((ext_vector_type(8))) short;
+        const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o_acc[db] = Mfma16<T16>::mfma(__builtin_bit_cast(frag_t, a8), pfrag, o_acc[db]);
+        if constexpr (T16 == FI_DTYPE_BF16)
+          o_acc[db] = Mfma16<T16>::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, wl), o_acc[db]);
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
 
   // ---- finalize and write (partial state or final output) ----
-  l_run += swap_halves(l_run);
+  l_run = reduce_rows<false>(l_run);
   const bool empty = !(l_run > 0.f);
   const float inv = empty ? 0.f : 1.0f / l_run;
   const float lse_v = empty ? FI_NEG_INF : m_run + fast_log2(l_run);
-  if (lq < G) {
-    const int qo_head = head0 + lq;
+  if (lc < G) {
+    const int qo_head = head0 + lc;
     const int64_t out_row = p.split_kv ? (int64_t)(p.o_indptr ? p.o_indptr[req] : 0) + kv_tile : req;
     const int64_t ob = (out_row * p.num_qo_heads + qo_head) * D;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db) {
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int d0 = 32 * db + 8 * r4 + 4 * lh;
-        if (p.split_kv) {
-          const f32x4 w = {o_acc[db][4 * r4] * inv, o_acc[db][4 * r4 + 1] * inv, o_acc[db][4 * r4 + 2] * inv,
-                           o_acc[db][4 * r4 + 3] * inv};
-          *(f32x4*)(p.tmp_o + ob + d0) = w;
-        } else {
-          const uint32_t w0 = pack2<T16>(o_acc[db][4 * r4] * inv, o_acc[db][4 * r4 + 1] * inv);
-          const uint32_t w1 = pack2<T16>(o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv);
-          *(u32x2*)((uint16_t*)p.o + ob + d0) = u32x2{w0, w1};
-        }
+      const int d0 = 16 * db + 4 * lg;
+      if (p.split_kv) {
+        *(f32x4*)(p.tmp_o + ob + d0) = o_acc[db] * inv;
+      } else {
+        const uint32_t w0 = pack2<T16>(o_acc[db][0] * inv, o_acc[db][1] * inv);
+        const uint32_t w1 = pack2<T16>(o_acc[db][2] * inv, o_acc[db][3] * inv);
+        *(u32x2*)((uint16_t*)p.o + ob + d0) = u32x2{w0, w1};
       }
     }
-    if (lh == 0) {
+    if (lg == 0) {
       if (p.split_kv) p.tmp_lse[out_row * p.num_qo_heads + qo_head] = lse_v;
       else if (p.lse) p.lse[out_row * p.num_qo_heads + qo_head] = lse_v;
     }

@@ -5,7 +5,14 @@
 namespace fi {
 
 template <int T16, int KVS, int D>
-static hipError_t launch(const DecodeKernelParams& p, int grid, hipStream_t stream) {
+static hipError_t launch(const DecodeKernelParams& p, int rope, int grid, hipStream_t stream) {
+  if (rope) {
+    if (p.indices)
+      decode_mfma_kernel<T16, KVS, D, true, true><<<dim3(grid), dim3(kDecodeThreads), 0, stream>>>(p);
+    else
+      decode_mfma_kernel<T16, KVS, D, false, true><<<dim3(grid), dim3(kDecodeThreads), 0, stream>>>(p);
+    return hipGetLastError();
+  }
   if (p.indices)
     decode_mfma_kernel<T16, KVS, D, true><<<dim3(grid), dim3(kDecodeThreads), 0, stream>>>(p);
   else
@@ -13,10 +20,10 @@ static hipError_t launch(const DecodeKernelParams& p, int grid, hipStream_t stre
   return hipGetLastError();
 }
 
-hipError_t decode_mfma_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int grid,
+hipError_t decode_mfma_launch(const DecodeKernelParams& p, int q_dtype, int kv_dtype, int head_dim, int rope, int grid,
                               hipStream_t stream) {
 #define FI_CASE(T, K, D) \
-  if (q_dtype == T && kv_dtype == K && head_dim == D) return launch<T, K, D>(p, grid, stream);
+  if (q_dtype == T && kv_dtype == K && head_dim == D) return launch<T, K, D>(p, rope, grid, stream);
 #define FI_ROW(T, K) FI_CASE(T, K, 64) FI_CASE(T, K, 128)
   FI_ROW(FI_DTYPE_F16, FI_DTYPE_F16)
   FI_ROW(FI_DTYPE_F16, FI_DTYPE_FP8_E4M3)

@@ -21,6 +21,13 @@ def tol(dtype):
     return dict(rtol=1e-3, atol=1e-3)
 
 
+def rope_rt(q_dtype, head_dim):
+    """rope_round_dtype for the oracle: decode with fused RoPE runs on the matrix-core kernel for head_dim 64 / 128,
+    which rounds the rotated q / k to the 16-bit type (as the reference's tensor-core decode = its prefill kernel
+    does, prefill.cuh:465-612); other head dims stay on the VALU kernel, which rotates in f32 (decode.cuh:445-466)."""
+    return q_dtype if head_dim in (64, 128) else None
+
+
 def make_paged(batch, kv_lens, page_size, hkv, d, dtype, layout, seed, shuffle=True, extra_pages=3):
     g = torch.Generator().manual_seed(seed)
     pages = [max(0, -(-l // page_size)) for l in kv_lens]
@@ -138,7 +145,8 @@ def test_batch_decode_pos_encoding(mode, d):
     (o, lse), _ = run_batch_decode(q, cache, "NHD", indptr, indices, last, hq, hkv, d, page_size,
                                    pos_encoding_mode=mode, rope_theta=1e4, rope_scale=1.0)
     o_ref, lse_ref = R.batch_decode_ref(q.float(), cache.float(), "NHD", indptr, indices, last,
-                                        pos_encoding_mode=mode)
+                                        pos_encoding_mode=mode,
+                                        rope_round_dtype=rope_rt(torch.float16, d) if mode == "ROPE_LLAMA" else None)
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=2e-3, atol=2e-3)
 
@@ -251,7 +259,8 @@ def test_single_decode_c1_config_and_rope():
     o_ref, _ = R.single_decode_ref(q.float(), k.float(), v.float())
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
     o = flashinfer.single_decode_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), pos_encoding_mode="ROPE_LLAMA")
-    o_ref, _ = R.single_decode_ref(q.float(), k.float(), v.float(), pos_encoding_mode="ROPE_LLAMA")
+    o_ref, _ = R.single_decode_ref(q.float(), k.float(), v.float(), pos_encoding_mode="ROPE_LLAMA",
+                                   rope_round_dtype=rope_rt(torch.float16, 128))
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
 
 
@@ -362,3 +371,21 @@ def test_single_decode_head_dim_512():
     o_ref, lse_ref = R.single_decode_ref(q.float(), k.float(), v.float())
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_decode_suite_through_r1_kernel_choice():
+    """FI_DECODE_MFMA16=0: groups of <= 4 heads back on the VALU kernel, wider ones on the 32x32x16 matrix-core
+    kernel (the default sends every group of <= 16 heads to decode_mfma16_kernel.h).  The switch is read once per
+    process, so the suite runs in a child."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("FI_DECODE_MFMA16") == "0":
+        pytest.skip("already the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FI_DECODE_MFMA16="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_decode_gpu.py"), "-x", "-q",
+                        "-p", "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

@@ -11,6 +11,7 @@ import torch
 from oracle import attention_ref as R
 from test_decode_gpu import make_paged, tol
 from test_prefill_gpu import ptol
+from test_decode_gpu import rope_rt
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -41,7 +42,7 @@ def test_fuzz_batch_decode(seed):
     variant = rng.choice(["plain", "plain", "rope", "alibi", "window", "softcap"])
     kw, okw = {}, {}
     if variant == "rope":
-        kw, okw = dict(pos_encoding_mode="ROPE_LLAMA"), dict(pos_encoding_mode="ROPE_LLAMA")
+        kw, okw = dict(pos_encoding_mode="ROPE_LLAMA"), dict(pos_encoding_mode="ROPE_LLAMA", rope_round_dtype=rope_rt(qdt, d))
     elif variant == "alibi":
         kw, okw = dict(pos_encoding_mode="ALIBI"), dict(pos_encoding_mode="ALIBI")
     elif variant == "window":
