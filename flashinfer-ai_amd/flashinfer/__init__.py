@@ -28,6 +28,7 @@ from .decode import single_decode_with_kv_cache as single_decode_with_kv_cache
 from .gemm import gemm_fp8_nt_groupwise as gemm_fp8_nt_groupwise
 from .gemm import group_gemm_fp8_nt_groupwise as group_gemm_fp8_nt_groupwise
 from .page import append_paged_kv_cache as append_paged_kv_cache
+from .page import apply_rope_append_paged_kv_cache as apply_rope_append_paged_kv_cache
 from .page import get_batch_indices_positions as get_batch_indices_positions
 from .page import get_seq_lens as get_seq_lens
 from .prefill import (

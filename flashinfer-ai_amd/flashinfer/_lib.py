@@ -203,6 +203,7 @@ EXPORTED_SYMBOLS = [
     "fi_get_batch_indices_positions",
     "fi_append_paged_kv_cache",
     "fi_apply_rope_pos_ids",
+    "fi_apply_rope_append_paged_kv_cache",
     "fi_rope_positions_from_indptr",
     "fi_packbits",
     "fi_segment_packbits",
@@ -241,6 +242,7 @@ def lib() -> C.CDLL:
     l.fi_get_batch_indices_positions.argtypes = [vp, vp, i32, i32, vp, vp, vp]
     l.fi_append_paged_kv_cache.argtypes = [vp, vp, C.c_int64, C.c_int64, C.c_int64, C.c_int64, vp, vp, i32, C.POINTER(PagedKV), vp]
     l.fi_apply_rope_pos_ids.argtypes = [C.POINTER(RopeParams), vp]
+    l.fi_apply_rope_append_paged_kv_cache.argtypes = [C.POINTER(RopeParams), vp, C.c_int64, C.c_int64, vp, vp, C.POINTER(PagedKV), vp]
     l.fi_rope_positions_from_indptr.argtypes = [vp, vp, i32, i32, vp, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(l, name)

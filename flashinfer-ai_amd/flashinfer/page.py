@@ -3,7 +3,7 @@ K/V append scatter that builds the caches the attention path reads."""
 from __future__ import annotations
 
 import ctypes as C
-from typing import Tuple, Union
+from typing import Optional, Tuple, Union
 
 import torch
 
@@ -121,3 +121,87 @@ def append_paged_kv_cache(
             ),
             "append_paged_kv_cache",
         )
+
+
+def apply_rope_append_paged_kv_cache(
+    q: torch.Tensor,
+    append_key: torch.Tensor,
+    append_value: torch.Tensor,
+    batch_indices: torch.Tensor,
+    positions: torch.Tensor,
+    paged_kv_cache: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]],
+    kv_indices: torch.Tensor,
+    kv_indptr: torch.Tensor,
+    kv_last_page_len: torch.Tensor,
+    kv_layout: str = "NHD",
+    rotary_dim: Optional[int] = None,
+    interleave: bool = False,
+    rope_scale: float = 1,
+    rope_theta: float = 1e4,
+    pos_ids: Optional[torch.Tensor] = None,
+    q_out: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    r"""RoPE fused with the cache append: ``apply_rope_pos_ids(q, append_key, pos_ids)`` followed by
+    ``append_paged_kv_cache(k_rope, append_value, ...)`` in one kernel -- every rotated key row is written once,
+    straight into its page, instead of out to a temporary and back in (the serving-loop step right before the
+    attention path).  Returns the rotated queries (``q_out`` if given; pass ``q_out=q`` for
+    in place).  ``pos_ids`` defaults to ``positions`` (the row's position in its sequence); the cache must have the
+    dtype of ``append_key``.  Bit-identical to the two calls it replaces.
+    (ref: flashinfer/rope.py:321-420 apply_rope_pos_ids, flashinfer/page.py:299-425 append_paged_kv_cache)"""
+    _check_kv_layout(kv_layout)
+    for t, name in ((q, "q"), (append_key, "append_key"), (append_value, "append_value")):
+        _lib.require_gpu_tensor(t, name)
+    k_cache, v_cache = _unpack_paged_kv_cache(paged_kv_cache, kv_layout)
+    if append_key.dtype != k_cache.dtype or append_value.dtype != v_cache.dtype or q.dtype != append_key.dtype:
+        raise ValueError("q / append_key / append_value dtype must match the cache dtype")
+    if q.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("q and append_key must be float16 or bfloat16")
+    if append_key.dim() != 3 or append_key.shape != append_value.shape or q.dim() != 3:
+        raise ValueError("q, append_key and append_value must be [nnz, heads, head_dim]")
+    page_size, num_kv_heads, head_dim, stride_page, stride_n, stride_h = paged_kv_strides(k_cache, v_cache, kv_layout)
+    if append_key.shape[1] != num_kv_heads or append_key.shape[2] != head_dim or q.shape[2] != head_dim or \
+            q.shape[0] != append_key.shape[0]:
+        raise ValueError("q / append_key shape does not match the cache")
+    if q.stride(-1) != 1:
+        q = q.contiguous()
+    if append_key.stride(-1) != 1:
+        append_key = append_key.contiguous()
+    if append_value.stride(-1) != 1:
+        append_value = append_value.contiguous()
+    if q_out is None:
+        q_out = torch.empty_like(q)
+    elif q_out.shape != q.shape or q_out.dtype != q.dtype or q_out.stride(-1) != 1:
+        raise ValueError("q_out must match q")
+    dev = k_cache.device
+    batch_indices = batch_indices.to(device=dev, dtype=torch.int32).contiguous()
+    positions = positions.to(device=dev, dtype=torch.int32).contiguous()
+    pos_ids = positions if pos_ids is None else pos_ids.to(device=dev, dtype=torch.int32).contiguous()
+    kv_indices = kv_indices.to(device=dev, dtype=torch.int32).contiguous()
+    kv_indptr = kv_indptr.to(device=dev, dtype=torch.int32).contiguous()
+    nnz = append_key.shape[0]
+    if batch_indices.numel() != nnz or positions.numel() != nnz or pos_ids.numel() != nnz:
+        raise ValueError("batch_indices, positions and pos_ids must have nnz entries")
+    kv = _lib.PagedKV(
+        k_data=k_cache.data_ptr(), v_data=v_cache.data_ptr(), indptr=kv_indptr.data_ptr(),
+        indices=kv_indices.data_ptr(), last_page_len=None, rope_pos_offset=None, stride_page=stride_page,
+        stride_n=stride_n, stride_h=stride_h, page_size=page_size, num_kv_heads=num_kv_heads,
+        head_dim=head_dim, batch_size=kv_indptr.numel() - 1, dtype=_lib.fi_dtype(k_cache.dtype),
+    )
+    params = _lib.RopeParams(
+        q=q.data_ptr(), k=append_key.data_ptr(), q_out=q_out.data_ptr(), k_out=None, pos_ids=pos_ids.data_ptr(),
+        cos_sin_cache=None, q_stride_n=q.stride(0), q_stride_h=q.stride(1), k_stride_n=append_key.stride(0),
+        k_stride_h=append_key.stride(1), qo_stride_n=q_out.stride(0), qo_stride_h=q_out.stride(1), ko_stride_n=0,
+        ko_stride_h=0, nnz=nnz, num_q_heads=q.shape[1], num_k_heads=num_kv_heads, head_dim=head_dim,
+        rotary_dim=head_dim if rotary_dim is None else rotary_dim, interleave=int(interleave),
+        dtype=_lib.fi_dtype(q.dtype), rope_rcp_scale=1.0 / rope_scale, rope_rcp_theta=1.0 / rope_theta,
+        smooth_a=0.0, smooth_b=0.0,
+    )
+    with torch.cuda.device(dev):
+        _lib.check(
+            _lib.lib().fi_apply_rope_append_paged_kv_cache(
+                C.byref(params), append_value.data_ptr(), append_value.stride(0), append_value.stride(1),
+                batch_indices.data_ptr(), positions.data_ptr(), C.byref(kv), _lib.current_stream(dev),
+            ),
+            "apply_rope_append_paged_kv_cache",
+        )
+    return q_out

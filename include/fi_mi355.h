@@ -376,6 +376,15 @@ typedef struct fi_rope_params {
 } fi_rope_params_t;
 
 FI_API int fi_apply_rope_pos_ids(const fi_rope_params_t* params, fi_stream_t stream);
+/* RoPE fused with the cache append ("fused RoPE-then-append"; the reference runs
+ * apply_rope_pos_ids (csrc/rope.cu) and then append_paged_kv_cache (csrc/page.cu:25-120) -- two passes over k):
+ * q is rotated into q_out as above; each rotated k row is written ONCE, into the paged cache at
+ * (batch_indices[i], positions[i]) (page.cuh:272-275), and the v row is copied beside it.  params->k_out and
+ * its strides are ignored; params->pos_ids are the rotation positions (normally == positions); the cache must
+ * have k's dtype.  Bit-identical to the two calls it replaces. */
+FI_API int fi_apply_rope_append_paged_kv_cache(const fi_rope_params_t* params, const void* append_value,
+                                        int64_t v_stride_n, int64_t v_stride_h, const int32_t* batch_indices,
+                                        const int32_t* positions, const fi_paged_kv_t* kv, fi_stream_t stream);
 /* pos_ids[i] = offsets[b] + i - indptr[b] for indptr[b] <= i < indptr[b+1] (ref: pos_enc.cuh:540-575) */
 FI_API int fi_rope_positions_from_indptr(const int32_t* indptr, const int32_t* offsets, int32_t batch_size,
                                   int32_t nnz, int32_t* pos_ids, fi_stream_t stream);

@@ -272,3 +272,45 @@ def test_serving_loop_example_runs_and_matches_flat_attention():
     out, o1 = mod.main(batch=3, prompt_len=70, new_tokens=5, hq=8, hkv=2, d=128, page_size=16, dtype=torch.float16)
     assert out.shape == (3 * 70, 8, 128) and o1.shape == (3, 8, 128)
     assert torch.isfinite(out.float()).all() and torch.isfinite(o1.float()).all()
+
+
+@pytest.mark.parametrize("layout", ["NHD", "HND"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rotary_dim,interleave,d", [(None, False, 128), (64, False, 128), (None, True, 64), (32, True, 64)])
+def test_fused_rope_append_equals_rope_then_append(layout, dtype, rotary_dim, interleave, d):
+    """apply_rope_append_paged_kv_cache == apply_rope_pos_ids + append_paged_kv_cache, bit for bit (cache contents
+    and rotated q), on a shuffled page table with a ragged batch (prefill chunk, then one decode token each)."""
+    import flashinfer
+
+    torch.manual_seed(1)
+    hkv, hq, ps = 2, 6, 8
+    lens0 = [45, 8, 25, 1]
+    b = len(lens0)
+    max_pages = 40
+    shape = (max_pages, 2, ps, hkv, d) if layout == "NHD" else (max_pages, 2, hkv, ps, d)
+    cache_a = torch.zeros(shape, dtype=dtype, device=DEV)
+    cache_b = torch.zeros(shape, dtype=dtype, device=DEV)
+    final = [l + 1 for l in lens0]
+    pages = [-(-l // ps) for l in final]
+    indptr = torch.tensor([0] + list(torch.tensor(pages).cumsum(0)), dtype=torch.int32, device=DEV)
+    indices = torch.randperm(max_pages)[: int(indptr[-1])].to(torch.int32).to(DEV)
+    seq_so_far = [0] * b
+    for step_lens in (lens0, [1] * b):
+        nnz = sum(step_lens)
+        q = torch.randn(nnz, hq, d).to(dtype).to(DEV)
+        k_new = torch.randn(nnz, hkv, d).to(dtype).to(DEV)
+        v_new = torch.randn(nnz, hkv, d).to(dtype).to(DEV)
+        seq_after = [s + a for s, a in zip(seq_so_far, step_lens)]
+        append_indptr = torch.tensor([0] + list(torch.tensor(step_lens).cumsum(0)), dtype=torch.int32, device=DEV)
+        bi, pos = flashinfer.get_batch_indices_positions(append_indptr, torch.tensor(seq_after), nnz)
+        last = torch.tensor([(l - 1) % ps + 1 for l in seq_after], dtype=torch.int32, device=DEV)
+        q_ref, k_rot = flashinfer.apply_rope_pos_ids(q, k_new, pos, rotary_dim=rotary_dim, interleave=interleave,
+                                                     rope_scale=2.0, rope_theta=5e4)
+        flashinfer.append_paged_kv_cache(k_rot, v_new, bi, pos, cache_a, indices, indptr, last, kv_layout=layout)
+        q_out = flashinfer.apply_rope_append_paged_kv_cache(q, k_new, v_new, bi, pos, cache_b, indices, indptr, last,
+                                                            kv_layout=layout, rotary_dim=rotary_dim,
+                                                            interleave=interleave, rope_scale=2.0, rope_theta=5e4)
+        assert torch.equal(q_out.view(torch.int16), q_ref.view(torch.int16))
+        assert torch.equal(cache_a.view(torch.int16), cache_b.view(torch.int16))
+        seq_so_far = seq_after
+    assert cache_b.float().abs().sum() > 0
