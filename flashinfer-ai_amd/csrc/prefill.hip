@@ -20,7 +20,7 @@ typedef hipError_t (*prefill_launch_fn)(const PrefillKernelParams&, int, hipStre
 FI_PF_DECL_D(0, 0, 0) FI_PF_DECL_D(0, 2, 0) FI_PF_DECL_D(0, 3, 0)
 FI_PF_DECL_D(1, 1, 1) FI_PF_DECL_D(1, 2, 1) FI_PF_DECL_D(1, 3, 1)
 // fp8 q + fp8 kv (ref FA3 fp8 path), output type picks the compute type
-FI_PF_DECL_D(0, 2, 2) FI_PF_DECL_D(1, 2, 2)
+FI_PF_DECL_D(0, 2, 2) FI_PF_DECL_D(1, 2, 2) FI_PF_DECL_D(0, 3, 3) FI_PF_DECL_D(1, 3, 3)
 #undef FI_PF_DECL
 #undef FI_PF_DECL_D
 
@@ -49,7 +49,7 @@ static prefill_launch_fn find_prefill(int t16, int kvs, int qs, int d) {
   }
   FI_TRY(0, 0, 0) FI_TRY(0, 2, 0) FI_TRY(0, 3, 0)
   FI_TRY(1, 1, 1) FI_TRY(1, 2, 1) FI_TRY(1, 3, 1)
-  FI_TRY(0, 2, 2) FI_TRY(1, 2, 2)
+  FI_TRY(0, 2, 2) FI_TRY(1, 2, 2) FI_TRY(0, 3, 3) FI_TRY(1, 3, 3)
 #undef FI_TRY
   return nullptr;
 }
@@ -248,8 +248,8 @@ static int check_prefill_dtypes(const char* who, int q_dt, int kv_dt, int o_dt) 
     FI_REQUIRE(kv_dt == q_dt || kv_dt == FI_DTYPE_FP8_E4M3 || kv_dt == FI_DTYPE_FP8_E5M2,
                "%s: kv dtype must equal q dtype or be fp8", who);
   } else {
-    FI_REQUIRE(q_dt == FI_DTYPE_FP8_E4M3 && kv_dt == FI_DTYPE_FP8_E4M3,
-               "%s: fp8 attention needs e4m3 q, k and v", who);
+    FI_REQUIRE((q_dt == FI_DTYPE_FP8_E4M3 || q_dt == FI_DTYPE_FP8_E5M2) && kv_dt == q_dt,
+               "%s: fp8 attention needs q, k and v of one fp8 type (e4m3 or e5m2)", who);
   }
   return 0;
 }
@@ -361,7 +361,7 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.window_left = a->window_left;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
   kp.o_dtype = a->o_dtype;
-  kp.fp8_p_quant = a->q_dtype == FI_DTYPE_FP8_E4M3;
+  kp.fp8_p_quant = a->q_dtype == FI_DTYPE_FP8_E4M3 || a->q_dtype == FI_DTYPE_FP8_E5M2;
   kp.logits_soft_cap = a->logits_soft_cap > 0.f ? a->logits_soft_cap : 0.f;
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
@@ -440,7 +440,7 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   kp.window_left = a->window_left;
   kp.use_alibi = a->pos_encoding_mode == FI_POS_ALIBI;
   kp.o_dtype = a->o_dtype;
-  kp.fp8_p_quant = a->q_dtype == FI_DTYPE_FP8_E4M3;
+  kp.fp8_p_quant = a->q_dtype == FI_DTYPE_FP8_E4M3 || a->q_dtype == FI_DTYPE_FP8_E5M2;
   kp.logits_soft_cap = a->logits_soft_cap > 0.f ? a->logits_soft_cap : 0.f;
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;

@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   using frag_t = typename M::frag;
   constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
   constexpr bool Q_FP8 = (QS == FI_DTYPE_FP8_E4M3 || QS == FI_DTYPE_FP8_E5M2);
+  [[maybe_unused]] constexpr float kPScale = (QS == FI_DTYPE_FP8_E5M2) ? 57344.f : 448.f;
   constexpr bool P_HI_LO = SPLIT_P && T16 == FI_DTYPE_BF16 && !Q_FP8;
   [[maybe_unused]] constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
   constexpr int ROWB = D * 2;             // bytes per row of the 16-bit LDS images
@@ -675,11 +676,20 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float a = s_acc[kbk][8 * s2 + 2 * j], b = s_acc[kbk][8 * s2 + 2 * j + 1];
-            if constexpr (Q_FP8) {  // ref: hopper/variants.cuh:84-90 -- P * 448 rounded to e4m3
-              const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a * 448.f, b * 448.f, 0, false);
-              const f32x2 back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
-              a = back[0];
-              b = back[1];
+            if constexpr (Q_FP8) {
+              // ref: hopper/variants.cuh:71-90 -- P * max(fp8 type) rounded to the q/k/v type (448 e4m3,
+              // 57344 e5m2), mainloop_mma.cuh:173 convert_type<DTypeKV>
+              if constexpr (QS == FI_DTYPE_FP8_E4M3) {
+                const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a * kPScale, b * kPScale, 0, false);
+                const f32x2 back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+                a = back[0];
+                b = back[1];
+              } else {
+                const int pk = __builtin_amdgcn_cvt_pk_bf8_f32(a * kPScale, b * kPScale, 0, false);
+                const f32x2 back = __builtin_amdgcn_cvt_pk_f32_bf8(pk, false);
+                a = back[0];
+                b = back[1];
+              }
             }
             w[j] = pack2<T16>(a, b);
             if constexpr (P_HI_LO) {
@@ -724,7 +734,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   l_run += swap_halves(l_run);
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
-  if constexpr (Q_FP8) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / 448.f;
+  if constexpr (Q_FP8) inv *= (p.scale_v ? p.scale_v[kv_head] : 1.f) / kPScale;
   else if (p.scale_v) inv *= p.scale_v[kv_head];
   if (row_valid && split) {
     // partial state of this kv chunk: normalised f32 o + base-2 lse (ref: prefill.cuh:2378-2403)

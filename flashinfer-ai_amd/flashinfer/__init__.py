@@ -59,4 +59,4 @@ from .rope import (
 )
 from .utils import next_positive_power_of_2 as next_positive_power_of_2
 
-__version__ = "0.3.1+mi355x.r1"
+__version__ = "0.3.1+mi355x.r2"
