@@ -375,8 +375,10 @@ extern "C" FI_API int fi_batch_decode_run(void* float_ws, size_t float_ws_bytes,
   kp.kv_stride_n = kv.stride_n;
   kp.kv_stride_h = kv.stride_h;
   const bool rope = a->pos_encoding_mode == FI_POS_ROPE_LLAMA;
+  // ALiBi and the logits soft cap exist in the 16x16x32 kernel only
+  const bool plain_logits = a->pos_encoding_mode != FI_POS_ALIBI && !(a->logits_soft_cap > 0.f);
   const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, kv.dtype, kv.head_dim, kv.page_size, rope) &&
-                        a->pos_encoding_mode != FI_POS_ALIBI && !(a->logits_soft_cap > 0.f) &&
+                        (plain_logits || mfma16_decode(kp.group_size, rope)) &&
                         kv.stride_page < (1ll << 31) && kv.stride_n < (1ll << 31);
   if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   kp.num_items = (int32_t)(padded * kv.num_kv_heads * kp.head_tiles);
@@ -472,8 +474,9 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   kp.rope_rcp_theta = a->rope_rcp_theta;
 
   const bool rope = a->pos_encoding_mode == FI_POS_ROPE_LLAMA;
+  const bool plain_logits = a->pos_encoding_mode != FI_POS_ALIBI && !(a->logits_soft_cap > 0.f);
   const bool use_mfma = mfma_decode_shape(kp.group_size, a->q_dtype, a->kv_dtype, a->head_dim, vpage, rope) &&
-                        a->pos_encoding_mode != FI_POS_ALIBI && !(a->logits_soft_cap > 0.f) &&
+                        (plain_logits || mfma16_decode(kp.group_size, rope)) &&
                         kp.kv_stride_page < (1ll << 31);
   if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   // split-KV so that the chip is filled (ref: decode.cuh:689-733, kv_len > 256 -> chunks >= 256)

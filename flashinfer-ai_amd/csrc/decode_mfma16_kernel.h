@@ -166,7 +166,13 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128 && KVS != T1
       }
     }
   }
-  const float c_log2 = p.sm_scale * kLog2e;
+  // logits: plain -> exp2 argument = s * sm_scale * log2(e) (folded into the FMA below).  ALiBi / soft cap (ref:
+  // variants.cuh:67-76 -- bias with qo_idx = 0 as the decode kernels pass it, decode.cuh:93-94, then the cap) are
+  // applied to the 8 logits a lane holds per tile and leave them in base-2 units (c = 1).
+  const bool general = p.use_alibi || p.logits_soft_cap > 0.f;
+  const float c_log2 = general ? 1.0f : p.sm_scale * kLog2e;
+  const float slope = p.use_alibi ? p.alibi_slopes[head] : 0.f;
+  const float inv_cap = p.logits_soft_cap > 0.f ? 1.0f / p.logits_soft_cap : 0.f;
 
   // ---- staging: pass ps covers rows ps * RPP + lane / GCH, cache chunk lane % GCH ----
   const int st_row = lane / GCH, st_ch = lane % GCH;
@@ -343,6 +349,17 @@ __global__ void __launch_bounds__(kDecodeThreads, (ROPE && D == 128 && KVS != T1
           const u32x4 a = *(const u32x4*)(kb + k_rd[ks] + h * 16 * ROWB);
           s_acc[h] = Mfma16<T16>::mfma(__builtin_bit_cast(frag_t, a), qf[ks], s_acc[h]);
         }
+      }
+      if (general) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float t = s_acc[h][j] * p.sm_scale;
+            if (p.use_alibi) t += slope * (float)(tile0 + 16 * h + 4 * lg + j);
+            if (p.logits_soft_cap > 0.f) t = p.logits_soft_cap * fast_tanh(t * inv_cap);
+            s_acc[h][j] = t * kLog2e;
+          }
       }
       if (tile0 + kTile > chunk_end || tile0 < win_start) {
         // register j of half h is kv row 16 h + 4 g + j; visible rows are [win_start, chunk_end)
