@@ -211,7 +211,7 @@ def secondary_workloads(device):
     out.append({"workload": "C4: group_gemm_fp8_nt_groupwise 8 experts M=4096 N=14336 K=4096 block=128", "ms": ms,
                 "value": flops / ms / 1e9, "unit": "TFLOP/s", "dtype": "fp8_e4m3",
                 "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 5000.0, "unit": "TFLOP/s",
-                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::group_gemm_fp8_dma_kernel"},
+                             "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::group_gemm_fp8_big_kernel"},
                 "l2_flush_between_iters": True, "cpu_baseline": cpu_baseline_c4(G, m, n, k)})
     return out
 
