@@ -294,6 +294,12 @@ def c5_cascade(device, world, rank, dist, iters=200, warm=30):
 
 
 def main():
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner to stdout
+    # when its communicator comes up), so file descriptor 1 is pointed at stderr for the whole run and the result
+    # line goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -433,7 +439,8 @@ def main():
                 line["secondary"] = secondary_workloads(device)
             except Exception as exc:  # the headline line must survive a failure of the side measurements
                 line["secondary"] = {"error": repr(exc)}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if distributed:
         dist.destroy_process_group()
 
