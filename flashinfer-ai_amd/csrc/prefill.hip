@@ -64,14 +64,18 @@ static int compute_type(int q_dt, int o_dt) {
 
 using namespace fi;
 
-extern "C" FI_API int fi_batch_prefill_plan(
+extern "C" FI_API int fi_batch_prefill_plan_tile(
     void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws, size_t int_ws_bytes,
     const int32_t* qo_indptr_h, const int32_t* kv_indptr_h, const int32_t* kv_len_arr_h,
     int32_t total_num_rows, int32_t batch_size, int32_t num_qo_heads, int32_t num_kv_heads,
     int32_t page_size, int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
     int32_t causal, int32_t window_left, int32_t fixed_split_size, int32_t disable_split_kv,
-    int64_t* plan_info_out, fi_stream_t stream) {
+    int32_t cta_tile_q, int64_t* plan_info_out, fi_stream_t stream) {
   (void)float_ws; (void)kv_indptr_h;
+  FI_REQUIRE(cta_tile_q == kTileQ || cta_tile_q == 2 * kTileQ,
+             "batch_prefill_plan: cta_tile_q must be %d or %d (the fp8-native kernel's 8-wave form)", kTileQ,
+             2 * kTileQ);
+  const int64_t tile_q = cta_tile_q;
   FI_REQUIRE(pinned_int_ws && qo_indptr_h && kv_len_arr_h && plan_info_out,
              "batch_prefill_plan: null argument");
   FI_REQUIRE(batch_size >= 0 && page_size > 0, "batch_prefill_plan: bad batch size / page size");
@@ -92,20 +96,20 @@ extern "C" FI_API int fi_batch_prefill_plan(
     const int64_t qo_len = qo_indptr_h[b + 1] - qo_indptr_h[b];
     FI_REQUIRE(qo_len >= 0, "batch_prefill_plan: qo_indptr must be non-decreasing");
     FI_REQUIRE(kv_len_arr_h[b] >= 0, "batch_prefill_plan: negative kv length");
-    q_tiles[b] = ceil_div<int64_t>(qo_len * group, kTileQ);
+    q_tiles[b] = ceil_div<int64_t>(qo_len * group, tile_q);
     kv_len[b] = std::max<int64_t>(kv_len_arr_h[b], 1);
     // sliding window: a q tile only walks the keys from its first row's window start on (the kernel
     // skips the rest), so chunks are cut from that span (ref: effective_kv_len_arr, scheduler.cuh:561-567)
     if (window_left >= 0)
-      kv_len[b] = std::min<int64_t>(kv_len[b], (int64_t)window_left + (causal ? kTileQ : qo_len) + kTileKV);
+      kv_len[b] = std::min<int64_t>(kv_len[b], (int64_t)window_left + (causal ? tile_q : qo_len) + kTileKV);
     total_q_tiles += q_tiles[b];
     max_kv_len = std::max(max_kv_len, kv_len[b]);
   }
   // resident workgroups (2 per CU) over the kv heads each item is launched for
   // (ref: max_batch_size_if_split = max_grid_size / num_kv_heads, scheduler.cuh:718)
-  const int64_t max_items = std::max<int64_t>((int64_t)fi_num_compute_units() * 2 / num_kv_heads, 1);
+  const int64_t max_items = std::max<int64_t>((int64_t)fi_num_compute_units() * (tile_q == kTileQ ? 2 : 1) / num_kv_heads, 1);
   const int64_t graph_bound =
-      ceil_div<int64_t>((int64_t)total_num_rows * group, kTileQ) + std::max(batch_size, 1) - 1;
+      ceil_div<int64_t>((int64_t)total_num_rows * group, tile_q) + std::max(batch_size, 1) - 1;
   // chunk sizes are multiples of one 64-row kv tile and at least 128 tokens (ref: min_kv_chunk_size)
   auto items_at = [&](int64_t chunk) {
     int64_t n = 0;
@@ -137,7 +141,7 @@ extern "C" FI_API int fi_batch_prefill_plan(
         int64_t lse_entries = entries;
         if (enable_cuda_graph)  // the fixed lse region of a graph plan (below)
           lse_entries = std::max(entries, std::max(items_at(chunk), std::max(max_items, graph_bound)) *
-                                              (ceil_div<int64_t>(kTileQ, group) + 1));
+                                              (ceil_div<int64_t>(tile_q, group) + 1));
         return (entries * num_qo_heads * head_dim_vo + lse_entries * num_qo_heads + 64) * (int64_t)sizeof(float);
       };
       while (kv_chunk < max_kv_len && ws_need(kv_chunk) > (int64_t)float_ws_bytes) kv_chunk *= 2;
@@ -204,11 +208,11 @@ extern "C" FI_API int fi_batch_prefill_plan(
   int64_t v_off = 0, s_off = 0;
   if (split_kv) {
     // lse region first, sized for the most partial states a launch of `padded` items can write (each
-    // (row, chunk) pair belongs to one item of <= kTileQ / G + 1 rows): with a fixed-shape (graph) plan
+    // (row, chunk) pair belongs to one item of <= tile_q / G + 1 rows): with a fixed-shape (graph) plan
     // both offsets are then the same for every plan, so a captured run() stays valid after a re-plan.
     // The outputs follow and may use the rest of the workspace.
     OffsetAllocator fa(float_ws_bytes);
-    const int64_t rows_per_item = ceil_div<int64_t>(kTileQ, group) + 1;
+    const int64_t rows_per_item = ceil_div<int64_t>(tile_q, group) + 1;
     const int64_t lse_entries =
         enable_cuda_graph ? std::max<int64_t>(entries, (int64_t)padded * rows_per_item) : std::max<int64_t>(entries, 1);
     s_off = fa.alloc((size_t)lse_entries * num_qo_heads * sizeof(float));
@@ -221,7 +225,7 @@ extern "C" FI_API int fi_batch_prefill_plan(
   plan_info_out[FI_PP_PADDED_BATCH_SIZE] = (int64_t)padded;
   plan_info_out[FI_PP_TOTAL_NUM_ROWS] = split_kv ? nrows_tab : total_num_rows;
   plan_info_out[FI_PP_KV_CHUNK_SIZE_PTR_OFFSET] = chunk_off;
-  plan_info_out[FI_PP_CTA_TILE_Q] = kTileQ;
+  plan_info_out[FI_PP_CTA_TILE_Q] = tile_q;
   plan_info_out[FI_PP_REQUEST_INDICES_OFFSET] = req_off;
   plan_info_out[FI_PP_QO_TILE_INDICES_OFFSET] = tile_off;
   plan_info_out[FI_PP_KV_TILE_INDICES_OFFSET] = kvt_off;
@@ -238,6 +242,19 @@ extern "C" FI_API int fi_batch_prefill_plan(
     FI_HIP_CALL(hipMemcpyAsync(int_ws, pinned_int_ws, ia.used, hipMemcpyHostToDevice,
                                (hipStream_t)stream));
   return 0;
+}
+
+extern "C" FI_API int fi_batch_prefill_plan(
+    void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws, size_t int_ws_bytes,
+    const int32_t* qo_indptr_h, const int32_t* kv_indptr_h, const int32_t* kv_len_arr_h,
+    int32_t total_num_rows, int32_t batch_size, int32_t num_qo_heads, int32_t num_kv_heads,
+    int32_t page_size, int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
+    int32_t causal, int32_t window_left, int32_t fixed_split_size, int32_t disable_split_kv,
+    int64_t* plan_info_out, fi_stream_t stream) {
+  return fi_batch_prefill_plan_tile(float_ws, float_ws_bytes, int_ws, pinned_int_ws, int_ws_bytes, qo_indptr_h,
+                                    kv_indptr_h, kv_len_arr_h, total_num_rows, batch_size, num_qo_heads,
+                                    num_kv_heads, page_size, enable_cuda_graph, head_dim_qk, head_dim_vo, causal,
+                                    window_left, fixed_split_size, disable_split_kv, kTileQ, plan_info_out, stream);
 }
 
 namespace fi {
@@ -366,7 +383,13 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
-  if (use_fp8_native(kp, a->q_dtype, kv.dtype, kv.head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA)) {
+  kp.tile_q = (int32_t)plan_info[FI_PP_CTA_TILE_Q];
+  const bool fp8_native = use_fp8_native(kp, a->q_dtype, kv.dtype, kv.head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA);
+  FI_REQUIRE(kp.tile_q == kTileQ || fp8_native,
+             "batch_prefill_paged_run: the plan was cut for %d-row q tiles (fi_batch_prefill_plan_tile), which only "
+             "the fp8-native kernel runs: e4m3 q/k/v, head_dim 128, no RoPE / ALiBi / soft cap / window / mask",
+             kp.tile_q);
+  if (fp8_native) {
     FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, stream));
   } else {
     FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
@@ -429,6 +452,7 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   kp.num_qo_heads = a->num_qo_heads;
   kp.num_kv_heads = a->num_kv_heads;
   kp.group_size = a->num_qo_heads / a->num_kv_heads;
+  kp.tile_q = kTileQ;
   kp.num_work = (int32_t)ceil_div<int64_t>((int64_t)a->qo_len * kp.group_size, kTileQ);
   kp.page_size = vpage;
   kp.page_div = FastDiv((uint32_t)vpage);

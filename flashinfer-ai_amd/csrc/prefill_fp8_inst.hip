@@ -9,10 +9,14 @@ namespace fi {
 template <int OUT16>
 static hipError_t launch_v2(const PrefillKernelParams& p, int grid, hipStream_t stream) {
   // group sizes 1 / 2 / 4: one query head per wave, logit scale in a scalar register (see the kernel)
-  if (p.group_size == 1 || p.group_size == 2 || p.group_size == 4)
-    batch_prefill_fp8_kernel<OUT16, true><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-  else
-    batch_prefill_fp8_kernel<OUT16, false><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+  const bool uni = p.group_size == 1 || p.group_size == 2 || p.group_size == 4;
+  if (p.tile_q == 2 * kTileQ) {  // plan cut for 256-row q tiles: the 8-wave form
+    if (uni) batch_prefill_fp8_kernel<OUT16, true, 8><<<dim3(grid), dim3(512), 0, stream>>>(p);
+    else batch_prefill_fp8_kernel<OUT16, false, 8><<<dim3(grid), dim3(512), 0, stream>>>(p);
+  } else {
+    if (uni) batch_prefill_fp8_kernel<OUT16, true, 4><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    else batch_prefill_fp8_kernel<OUT16, false, 4><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+  }
   return hipGetLastError();
 }
 
@@ -23,7 +27,7 @@ hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, hipSt
     const char* e = getenv("FI_PREFILL_FP8_V1");
     return e && atoi(e) != 0;
   }();
-  if (v1) {
+  if (v1 && p.tile_q == kTileQ) {
     if (out_dtype == FI_DTYPE_BF16)
       batch_prefill_fp8_v1_kernel<FI_DTYPE_BF16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
     else

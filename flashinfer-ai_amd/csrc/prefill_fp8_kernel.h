@@ -88,9 +88,15 @@ typedef const __attribute__((address_space(1))) void f8_gbl_void;
 // tokens), so the logit scale c = sm_scale * scale_q[head] * scale_k[kv head] * log2 e is wave-uniform and sits in a
 // scalar register: exp2's argument fma(s, c, -m) then reads two vector registers instead of three (a vector
 // instruction with three distinct vector sources issues at half rate: tools/ubench_issue2 measurements).
-template <int OUT16, bool UNI>
-__global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
+// NW: waves per workgroup.  4: 128 packed query rows, two workgroups per CU.  8 (plans cut with cta_tile_q = 256):
+// 256 rows share every K/V tile, so a wave issues two LDS-DMA pieces per 64-key step instead of four and the
+// page-id / row-offset tables are built once per 256 rows; one workgroup per CU, the same 8 waves.
+template <int OUT16, bool UNI, int NW>
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
   constexpr int D = 128;
+  constexpr int kThreads = NW * 64;
+  constexpr int kTQ = NW * 32;  // packed query rows per workgroup
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int DBLK = D / 32;
   // ONE static array for every LDS object: the compiler separates an LDS-DMA target from an LDS read by
   // constant offsets (and index ranges) inside one object; with a second object, or unbounded indices, it
@@ -145,8 +151,8 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
   const int packed_len = qo_len * G;
   // packed row (qo_idx * G + head) of this lane inside the workgroup's 128-row tile
   const int row_in_tile = UNI ? ((wave / G) * 32 + lq) * G + (wave % G) : wave * 32 + lq;
-  const int row0 = q_tile * kTileQ + (UNI ? (wave / G) * 32 * G : wave * 32);  // the wave's first packed row
-  const int pr = q_tile * kTileQ + row_in_tile;
+  const int row0 = q_tile * kTQ + (UNI ? (wave / G) * 32 * G : wave * 32);  // the wave's first packed row
+  const int pr = q_tile * kTQ + row_in_tile;
   const bool row_valid = pr < packed_len;
   const int prc = row_valid ? pr : (packed_len > 0 ? packed_len - 1 : 0);
   const int qo_idx = (int)fast_div((uint32_t)prc, p.group_div);
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
 
   int kv_end = kv_len;
   if (p.causal) {
-    const int last_pr = min(q_tile * kTileQ + kTileQ, packed_len) - 1;
+    const int last_pr = min(q_tile * kTQ + kTQ, packed_len) - 1;
     const int last_qo = last_pr >= 0 ? (int)fast_div((uint32_t)last_pr, p.group_div) : 0;
     kv_end = min(kv_len, max(0, kv_len - qo_len + last_qo + 1));
   }
@@ -242,7 +248,7 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
     int ids_base = (int)fast_div((uint32_t)min(tile_base * kTileKV, max(kv_len - 1, 0)), p.page_div);
     auto fill_ids = [&]() {
       if (p.kv_indices) {
-        for (int i = tid; i < kF8Ids; i += kPrefillThreads) {
+        for (int i = tid; i < kF8Ids; i += kThreads) {
           const int pg = ids_base + i;
           ids[i] = pg < num_pages ? p.kv_indices[page_begin + pg] : 0;
         }
@@ -268,16 +274,18 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
     // (dma_offsets, early in a step) and the four pieces are issued later (dma_issue), so that the LDS latency of
     // the table read does not sit at the top of the step
     auto dma_offsets = [&](int slot, uint64_t& off0, uint64_t& off1) {
-      off0 = tab[slot * kTileKV + st_row];
-      off1 = tab[slot * kTileKV + st_row + 32];
+      off0 = tab[slot * kTileKV + st_row];  // NW == 8: st_row covers all 64 rows, one K and one V piece per wave
+      off1 = NW == 4 ? tab[slot * kTileKV + st_row + 32] : 0;
     };
     auto dma_issue = [&](int stage, uint64_t off0, uint64_t off1) {
       char* const kdst = smem + stage * kF8KTile + wave * 1024;
       char* const vdst = kdst + kF8VOff;
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off0), (f8_lds_void*)(kdst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off1), (f8_lds_void*)(kdst + 4096), 16, 0, 0);
+      if constexpr (NW == 4)
+        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off1), (f8_lds_void*)(kdst + 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off0), (f8_lds_void*)(vdst), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off1), (f8_lds_void*)(vdst + 4096), 16, 0, 0);
+      if constexpr (NW == 4)
+        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off1), (f8_lds_void*)(vdst + 4096), 16, 0, 0);
     };
     auto dma_tile = [&](int slot, int stage) {
       uint64_t off0, off1;
@@ -287,13 +295,15 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
 
     fill_ids();
     __syncthreads();
-    make_tab(wave, wave);  // tables of tiles 0..3 (clamped)
+    if (wave < 4) make_tab(wave, wave);  // tables of tiles 0..3 (clamped)
     __syncthreads();
     dma_tile(0, 0);
     dma_tile(1, 1);
     dma_tile(2, 2);
-    // tiles 0 and 1 have landed (tile 2: 4 pieces in flight); wait + barrier as one statement (see the step)
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // tiles 0 and 1 have landed (tile 2: this wave's 4 (NW = 8: 2) pieces in flight); wait + barrier as one
+    // statement (see the step)
+    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
 
     // ---- building blocks ----
     const i32x8 q0 = qf[0], q1 = qf[1];
@@ -488,7 +498,11 @@ __global__ void __launch_bounds__(kPrefillThreads, 2) batch_prefill_fp8_kernel(c
       // K of tile t+2 (and everything older, V of tile t+1 included) of this wave's pieces landed; then the
       // workgroup barrier.  ONE asm statement: the s_barrier builtin alone is no memory fence for the compiler,
       // which would hoist the next step's LDS reads between the wait and the barrier.
-      if (!(FI_PF8_KO & 4)) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // (in flight afterwards: V of tile t+2 and both operands of tile t+3 -- 6 pieces, 3 with NW = 8)
+      if (!(FI_PF8_KO & 4)) {
+        if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
     };
     auto refill_if_needed = [&](int t_first, int t_last) {
       if (p.kv_indices && !(ids_cover(t_first + 4) && ids_cover(t_last + 4))) {  // uniform; rare

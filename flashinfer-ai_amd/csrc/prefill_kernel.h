@@ -80,6 +80,7 @@ struct PrefillKernelParams {
   int32_t use_alibi;
   int32_t o_dtype;      // FI_DTYPE_F16 / BF16
   int32_t fp8_p_quant;  // round P through e4m3 (fp8 Q path)
+  int32_t tile_q;       // packed query rows per workgroup the plan was cut for (128; 256: fp8-native 8-wave form)
   float logits_soft_cap;
   float sm_scale;
   float rope_rcp_scale, rope_rcp_theta;

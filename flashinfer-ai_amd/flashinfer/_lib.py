@@ -196,6 +196,7 @@ EXPORTED_SYMBOLS = [
     "fi_merge_states",
     "fi_variable_length_merge_states",
     "fi_batch_prefill_plan",
+    "fi_batch_prefill_plan_tile",
     "fi_batch_prefill_paged_run",
     "fi_single_prefill_run",
     "fi_gemm_fp8_nt_groupwise",
@@ -233,6 +234,7 @@ def lib() -> C.CDLL:
     l.fi_merge_states.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.fi_variable_length_merge_states.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     l.fi_batch_prefill_plan.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp] + [i32] * 12 + [i64p, vp]
+    l.fi_batch_prefill_plan_tile.argtypes = [vp, sz, vp, vp, sz, vp, vp, vp] + [i32] * 13 + [i64p, vp]
     l.fi_batch_prefill_paged_run.argtypes = [vp, sz, vp, sz, i64p, i32, C.POINTER(BatchPrefillParams), vp]
     l.fi_single_prefill_run.argtypes = [C.POINTER(SinglePrefillParams), vp, sz, vp]
     l.fi_gemm_fp8_nt_groupwise.argtypes = [vp] * 5 + [i32] * 10 + [vp]

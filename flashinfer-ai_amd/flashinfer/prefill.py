@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes as C
 import functools
 import math
+import os
 from typing import Any, List, Optional, Tuple, Union
 
 import torch
@@ -46,6 +47,23 @@ def _scale_tensor(x, n: int, device) -> Optional[torch.Tensor]:
     if x.numel() != n:
         raise ValueError(f"scale tensor must have {n} entries, got {x.numel()}")
     return x
+
+
+def _pick_cta_tile_q(q_dtype, kv_dtype, head_dim, pos_encoding_mode, logits_soft_cap, window_left, masked,
+                     qo_indptr_host, group_size, num_kv_heads) -> int:
+    """128, or 256 (fi_batch_prefill_plan_tile: the fp8-native kernel's 8-wave form) on request: FI_PREFILL_FP8_TILE=256
+    and a plan that cannot leave that kernel's coverage -- e4m3 q/k/v, head_dim 128, plain logits, no window / mask.
+    Measured at C3 the 256-row form is 4 % SLOWER (2.17 vs 2.08 ms: half the LDS-DMA instructions per query row, but
+    eight waves per barrier and coarser causal diagonals), so it is not chosen by default."""
+    if os.environ.get("FI_PREFILL_FP8_TILE") != "256":
+        return 128
+    if q_dtype != torch.float8_e4m3fn or kv_dtype != torch.float8_e4m3fn or head_dim != 128:
+        return 128
+    if pos_encoding_mode not in (None, "NONE") or (logits_soft_cap or 0) > 0 or (window_left is not None and window_left >= 0):
+        return 128
+    if masked or os.environ.get("FI_PREFILL_FP8_NATIVE", "1") == "0":
+        return 128
+    return 256
 
 
 def _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len,
@@ -427,10 +445,15 @@ class BatchPrefillWithPagedKVCacheWrapper:
             self._paged_kv_last_page_len_buf = paged_kv_last_page_len.to(self.device, non_blocking=non_blocking)
             total_rows_bound = total_num_rows
 
+        # q tile: 128 packed rows; 256 (the fp8-native kernel's 8-wave form) only on request, see _pick_cta_tile_q
+        cta_tile_q = _pick_cta_tile_q(
+            q_data_type, kv_data_type, head_dim_qk, pos_encoding_mode, logits_soft_cap, window_left,
+            self._custom_mask_buf is not None or prefix_len_ptr is not None, qo_indptr_host,
+            num_qo_heads // num_kv_heads, num_kv_heads)
         plan_info = (C.c_int64 * _lib.FI_PREFILL_PLAN_INFO_LEN)()
         with torch.cuda.device(self.device):
             _lib.check(
-                _lib.lib().fi_batch_prefill_plan(
+                _lib.lib().fi_batch_prefill_plan_tile(
                     self._float_workspace_buffer.data_ptr(),
                     self._float_workspace_buffer.numel() * self._float_workspace_buffer.element_size(),
                     self._int_workspace_buffer.data_ptr(),
@@ -439,7 +462,7 @@ class BatchPrefillWithPagedKVCacheWrapper:
                     qo_indptr_host.data_ptr(), paged_kv_indptr_host.data_ptr(), kv_lens_arr_host.data_ptr(),
                     total_rows_bound, batch_size, num_qo_heads, num_kv_heads, page_size,
                     int(self.is_cuda_graph_enabled), head_dim_qk, head_dim_vo, int(causal), window_left,
-                    -1 if fixed_split_size is None else fixed_split_size, int(disable_split_kv),
+                    -1 if fixed_split_size is None else fixed_split_size, int(disable_split_kv), cta_tile_q,
                     plan_info, _lib.current_stream(self.device),
                 ),
                 "BatchPrefillWithPagedKVCacheWrapper.plan",

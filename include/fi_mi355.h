@@ -239,6 +239,16 @@ FI_API int fi_batch_prefill_plan(void* float_ws, size_t float_ws_bytes, void* in
                           int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
                           int32_t causal, int32_t window_left, int32_t fixed_split_size,
                           int32_t disable_split_kv, int64_t* plan_info_out, fi_stream_t stream);
+/* The same planner for a caller-chosen q tile: cta_tile_q = 128 (every kernel; what fi_batch_prefill_plan uses) or
+ * 256 -- the 8-wave form of the fp8-native kernel (e4m3 q/k/v, head_dim 128, plain logits), which halves the K/V
+ * staging work per query row; run() rejects such a plan for anything that kernel does not cover. */
+FI_API int fi_batch_prefill_plan_tile(void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws,
+                          size_t int_ws_bytes, const int32_t* qo_indptr_h, const int32_t* kv_indptr_h,
+                          const int32_t* kv_len_arr_h, int32_t total_num_rows, int32_t batch_size,
+                          int32_t num_qo_heads, int32_t num_kv_heads, int32_t page_size,
+                          int32_t enable_cuda_graph, int32_t head_dim_qk, int32_t head_dim_vo,
+                          int32_t causal, int32_t window_left, int32_t fixed_split_size,
+                          int32_t disable_split_kv, int32_t cta_tile_q, int64_t* plan_info_out, fi_stream_t stream);
 
 typedef struct fi_batch_prefill_params {
   const void* q; /* [nnz_qo, num_qo_heads, head_dim] */

@@ -471,3 +471,21 @@ def test_single_prefill_splits_long_kv(causal, qo_len, kv_len):
     o = flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), custom_mask=mask.to(DEV))
     o_ref, _ = R.attention_ref(q.float(), k.float(), v.float(), custom_mask=mask)
     torch.testing.assert_close(o.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_fp8_prefill_through_the_256_row_tile_form():
+    """FI_PREFILL_FP8_TILE=256: plans cut with fi_batch_prefill_plan_tile(cta_tile_q = 256) and the 8-wave form of the
+    fp8-native kernel (not the default: 4 % slower at C3).  The switch is read at plan(), the fp8 tests run in a child."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("FI_PREFILL_FP8_TILE") == "256":
+        pytest.skip("already the child")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FI_PREFILL_FP8_TILE="256")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_prefill_gpu.py"),
+                        os.path.join(root, "tests", "test_graph_replan_gpu.py"), "-x", "-q", "-k", "fp8", "-p",
+                        "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
