@@ -10,9 +10,9 @@
 
 namespace fi {
 
-template <bool ROPE, bool GENERAL, bool SPLIT_P = false>
+template <bool ROPE, bool GENERAL, int PMODE = 0>
 static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
-  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE, GENERAL, SPLIT_P>;
+  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE, GENERAL, PMODE>;
   constexpr int smem = 2 * 2 * kTileKV * FI_PF_D * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -30,15 +30,21 @@ hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t strea
   const bool general = p.use_alibi || p.logits_soft_cap > 0.f || p.custom_mask != nullptr || p.prefix_len_ptr != nullptr;
 #if FI_PF_T16 == 1 && FI_PF_QS == 1  // FI_DTYPE_BF16 (an enumerator: not visible to the preprocessor)
   static_assert(FI_DTYPE_BF16 == 1, "bf16 tag");
-  // bf16: P as hi + lo halves unless FI_PREFILL_BF16_SINGLE_P=1 asks for the reference's single rounding
-  // (prefill.cuh:1263-1275 rounds P once; ~8 % faster, absolute error up to ~4e-3 on unit-variance V)
-  static const bool single = [] {
-    const char* e = getenv("FI_PREFILL_BF16_SINGLE_P");
-    return e && atoi(e) != 0;
+  // bf16: P.V on the f16 MFMA (prefill_kernel.h, PMODE 2) unless FI_PREFILL_BF16_P selects 0 = the reference's single
+  // bf16 rounding of P (prefill.cuh:962-985; absolute error up to ~4e-3 on unit-variance V) or 1 = hi + lo bf16 halves
+  // (no f16 range limit on V; 25 % slower).  FI_PREFILL_BF16_SINGLE_P=1 is the older spelling of 0.
+  static const int pmode = [] {
+    if (const char* e = getenv("FI_PREFILL_BF16_P")) return atoi(e);
+    const char* s1 = getenv("FI_PREFILL_BF16_SINGLE_P");
+    return (s1 && atoi(s1) != 0) ? 0 : 2;
   }();
-  if (!single) {
-    if (rope) return general ? launch<true, true, true>(p, stream) : launch<true, false, true>(p, stream);
-    return general ? launch<false, true, true>(p, stream) : launch<false, false, true>(p, stream);
+  if (pmode == 2) {
+    if (rope) return general ? launch<true, true, 2>(p, stream) : launch<true, false, 2>(p, stream);
+    return general ? launch<false, true, 2>(p, stream) : launch<false, false, 2>(p, stream);
+  }
+  if (pmode == 1) {
+    if (rope) return general ? launch<true, true, 1>(p, stream) : launch<true, false, 1>(p, stream);
+    return general ? launch<false, true, 1>(p, stream) : launch<false, false, 1>(p, stream);
   }
 #endif
   if (rope) return general ? launch<true, true>(p, stream) : launch<true, false>(p, stream);

@@ -168,9 +168,15 @@ __device__ __forceinline__ float round_through_e4m3(float x) {
 
 // T16: MFMA compute type; KVS: K/V storage dtype; QS: Q storage dtype; D: head_dim (64 / 128)
 // GENERAL: ALiBi / logits soft cap compiled in (kept out of the common instantiation's hot loop)
-// SPLIT_P: bf16 only -- P enters P.V as hi + lo bf16 halves (two MFMAs over the same V fragment, 16 mantissa
-//   bits) instead of one bf16 rounding (8 bits); see the P.V block
-template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL, bool SPLIT_P>
+// PMODE (bf16 q only; how P enters P.V -- a bf16 P carries 8 mantissa bits, which shows as ~2^-9 sum |p v| on
+// cancelling rows, 4e-3 on unit-variance V):
+//   0  P rounded once to bf16: the reference's arithmetic (prefill.cuh:962-985)
+//   1  P as hi + lo bf16 halves, two MFMAs over the same V fragment (16 mantissa bits; +50 % P.V MFMAs)
+//   2  P.V on the f16 MFMA: P rounded to f16 (11 bits, <= 2^6 by the deferred rescale) and V converted to f16 while
+//      it is staged (exact for |v| < 65504 -- larger values saturate there -- and free for an fp8 cache, which is
+//      converted anyway); QK^T stays on the bf16 MFMA.  The default: the 1e-3 bar at the cost of ~48 conversions
+//      per tile instead of 16 MFMAs + 80 vector instructions.
+template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL, int PMODE>
 // head_dim 256 keeps 128 accumulator + 64 query-fragment registers per lane: one wave per SIMD (512 registers)
 __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     batch_prefill_kernel(const PrefillKernelParams p) {
@@ -179,7 +185,10 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
   constexpr bool Q_FP8 = (QS == FI_DTYPE_FP8_E4M3 || QS == FI_DTYPE_FP8_E5M2);
   [[maybe_unused]] constexpr float kPScale = (QS == FI_DTYPE_FP8_E5M2) ? 57344.f : 448.f;
-  constexpr bool P_HI_LO = SPLIT_P && T16 == FI_DTYPE_BF16 && !Q_FP8;
+  constexpr bool P_HI_LO = PMODE == 1 && T16 == FI_DTYPE_BF16 && !Q_FP8;
+  constexpr bool PV_F16 = PMODE == 2 && T16 == FI_DTYPE_BF16 && !Q_FP8;
+  constexpr int TPV = PV_F16 ? FI_DTYPE_F16 : T16;  // operand type of the P.V MFMA
+  using MPV = MfmaType<TPV>;
   [[maybe_unused]] constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
   constexpr int ROWB = D * 2;             // bytes per row of the 16-bit LDS images
   constexpr int CPR = D / 8;              // 16-byte chunks per row
@@ -470,8 +479,20 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     for (int ps = 0; ps < NPASS; ++ps) {
       const int row = ps * RPP + st_row;
       u32x4 vw;
-      if constexpr (KV_FP8) vw = fp8x8_to_16<T16, KVS>(u32x2{st.r[ps][0], st.r[ps][1]});
-      else vw = st.r[ps];
+      if constexpr (KV_FP8) {
+        vw = fp8x8_to_16<TPV, KVS>(u32x2{st.r[ps][0], st.r[ps][1]});
+      } else if constexpr (PV_F16) {
+        // bf16 -> f16: exact inside f16's range (8 significant bits fit 11), saturating at 65504 beyond it
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t raw = st.r[ps][w];
+          const auto h2 = __builtin_amdgcn_cvt_pkrtz(__builtin_bit_cast(float, raw << 16),
+                                                     __builtin_bit_cast(float, raw & 0xffff0000u));
+          vw[w] = __builtin_bit_cast(uint32_t, h2);
+        }
+      } else {
+        vw = st.r[ps];
+      }
       *(u32x4*)(vb + v_lds_off(row, st_ch)) = vw;
     }
   };
@@ -692,7 +713,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
                 b = back[1];
               }
             }
-            w[j] = pack2<T16>(a, b);
+            w[j] = pack2<TPV>(a, b);
             if constexpr (P_HI_LO) {
               // A bf16 P carries 8 mantissa bits: with |o| << |v| (cancelling rows) the rounding shows as
               // ~2^-9 |p v| absolute, 4e-3 on unit-variance V.  The residual p - bf16(p) is exact in f32 and
@@ -702,7 +723,8 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
               w_lo[j] = pack2<T16>(a - a_hi, b - b_hi);
             }
           }
-          const frag_t pfrag = __builtin_bit_cast(frag_t, w);
+          using pv_frag_t = typename MPV::frag;
+          const pv_frag_t pfrag = __builtin_bit_cast(pv_frag_t, w);
 #pragma unroll
           for (int db = 0; db < DBLK; ++db) {
             const char* base = vb + (32 * kbk + 16 * s2) * ROWB + v_rd(db);
@@ -712,7 +734,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
                 (__attribute__((address_space(3))) s16x4*)(base + 8 * ROWB));
             using s16x8 = __attribute__((ext_vector_type(8))) short;
             const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), pfrag, o_acc[db]);
+            o_acc[db] = MPV::mfma(__builtin_bit_cast(pv_frag_t, a8), pfrag, o_acc[db]);
             if constexpr (P_HI_LO)
               o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, w_lo), o_acc[db]);
           }
