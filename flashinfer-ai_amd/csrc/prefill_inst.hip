@@ -10,9 +10,9 @@
 
 namespace fi {
 
-template <bool ROPE, bool GENERAL, int PMODE = 0>
+template <bool ROPE, int GEN, int PMODE = 0>
 static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
-  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE, GENERAL, PMODE>;
+  auto kern = batch_prefill_kernel<FI_PF_T16, FI_PF_KVS, FI_PF_QS, FI_PF_D, ROPE, GEN, PMODE>;
   constexpr int smem = 2 * 2 * kTileKV * FI_PF_D * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -26,8 +26,24 @@ static hipError_t launch(const PrefillKernelParams& p, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// feature mask of a run (prefill_kernel.h, GEN): a single feature without fused RoPE gets its own instantiation,
+// combinations (and every fused-RoPE run with a feature) the all-features one
+template <int PMODE>
+static hipError_t launch_features(const PrefillKernelParams& p, int rope, hipStream_t stream) {
+  const int gen = (p.use_alibi ? 1 : 0) | (p.logits_soft_cap > 0.f ? 2 : 0) | (p.custom_mask != nullptr ? 4 : 0) |
+                  (p.prefix_len_ptr != nullptr ? 8 : 0);
+  if (rope) return gen ? launch<true, 15, PMODE>(p, stream) : launch<true, 0, PMODE>(p, stream);
+  switch (gen) {
+    case 0: return launch<false, 0, PMODE>(p, stream);
+    case 1: return launch<false, 1, PMODE>(p, stream);
+    case 2: return launch<false, 2, PMODE>(p, stream);
+    case 4: return launch<false, 4, PMODE>(p, stream);
+    case 8: return launch<false, 8, PMODE>(p, stream);
+    default: return launch<false, 15, PMODE>(p, stream);
+  }
+}
+
 hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t stream) {
-  const bool general = p.use_alibi || p.logits_soft_cap > 0.f || p.custom_mask != nullptr || p.prefix_len_ptr != nullptr;
 #if FI_PF_T16 == 1 && FI_PF_QS == 1  // FI_DTYPE_BF16 (an enumerator: not visible to the preprocessor)
   static_assert(FI_DTYPE_BF16 == 1, "bf16 tag");
   // bf16: P.V on the f16 MFMA (prefill_kernel.h, PMODE 2) unless FI_PREFILL_BF16_P selects 0 = the reference's single
@@ -38,17 +54,10 @@ hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t strea
     const char* s1 = getenv("FI_PREFILL_BF16_SINGLE_P");
     return (s1 && atoi(s1) != 0) ? 0 : 2;
   }();
-  if (pmode == 2) {
-    if (rope) return general ? launch<true, true, 2>(p, stream) : launch<true, false, 2>(p, stream);
-    return general ? launch<false, true, 2>(p, stream) : launch<false, false, 2>(p, stream);
-  }
-  if (pmode == 1) {
-    if (rope) return general ? launch<true, true, 1>(p, stream) : launch<true, false, 1>(p, stream);
-    return general ? launch<false, true, 1>(p, stream) : launch<false, false, 1>(p, stream);
-  }
+  if (pmode == 2) return launch_features<2>(p, rope, stream);
+  if (pmode == 1) return launch_features<1>(p, rope, stream);
 #endif
-  if (rope) return general ? launch<true, true>(p, stream) : launch<true, false>(p, stream);
-  return general ? launch<false, true>(p, stream) : launch<false, false>(p, stream);
+  return launch_features<0>(p, rope, stream);
 }
 
 }  // namespace fi

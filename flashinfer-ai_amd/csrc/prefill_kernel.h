@@ -167,7 +167,11 @@ __device__ __forceinline__ float round_through_e4m3(float x) {
 }
 
 // T16: MFMA compute type; KVS: K/V storage dtype; QS: Q storage dtype; D: head_dim (64 / 128)
-// GENERAL: ALiBi / logits soft cap compiled in (kept out of the common instantiation's hot loop)
+// GEN: logits / mask features compiled in, a bit mask -- 1 ALiBi, 2 logits soft cap, 4 custom bit mask, 8 multi-item
+//   scoring.  0: the plain kernel.  A single bit: that feature only, unconditionally.  15: all four behind wave-uniform
+//   runtime tests -- which the compiler if-converts, so every element pays for every feature (a tanh, a mask bit
+//   extraction, two compares ...: 2.8x the vector instructions of the plain loop); it serves feature combinations
+//   and the fused-RoPE instantiations, the single-bit forms the common cases.
 // PMODE (bf16 q only; how P enters P.V -- a bf16 P carries 8 mantissa bits, which shows as ~2^-9 sum |p v| on
 // cancelling rows, 4e-3 on unit-variance V):
 //   0  P rounded once to bf16: the reference's arithmetic (prefill.cuh:962-985)
@@ -176,7 +180,7 @@ __device__ __forceinline__ float round_through_e4m3(float x) {
 //      it is staged (exact for |v| < 65504 -- larger values saturate there -- and free for an fp8 cache, which is
 //      converted anyway); QK^T stays on the bf16 MFMA.  The default: the 1e-3 bar at the cost of ~48 conversions
 //      per tile instead of 16 MFMAs + 80 vector instructions.
-template <int T16, int KVS, int QS, int D, bool ROPE, bool GENERAL, int PMODE>
+template <int T16, int KVS, int QS, int D, bool ROPE, int GEN, int PMODE>
 // head_dim 256 keeps 128 accumulator + 64 query-fragment registers per lane: one wave per SIMD (512 registers)
 __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     batch_prefill_kernel(const PrefillKernelParams p) {
@@ -184,6 +188,12 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   using frag_t = typename M::frag;
   constexpr bool KV_FP8 = (KVS == FI_DTYPE_FP8_E4M3 || KVS == FI_DTYPE_FP8_E5M2);
   constexpr bool Q_FP8 = (QS == FI_DTYPE_FP8_E4M3 || QS == FI_DTYPE_FP8_E5M2);
+  constexpr bool GENERAL = GEN != 0;
+  static_assert(GEN == 0 || GEN == 1 || GEN == 2 || GEN == 4 || GEN == 8 || GEN == 15, "feature mask");
+  // feature f is on: compiled in, and (only in the all-features form) asked for at run time
+  const bool f_alibi = (GEN & 1) && (GEN != 15 || p.use_alibi);
+  const bool f_cap = (GEN & 2) && (GEN != 15 || p.logits_soft_cap > 0.f);
+  const bool f_multi = (GEN & 8) && (GEN != 15 || p.prefix_len_ptr != nullptr);
   [[maybe_unused]] constexpr float kPScale = (QS == FI_DTYPE_FP8_E5M2) ? 57344.f : 448.f;
   constexpr bool P_HI_LO = PMODE == 1 && T16 == FI_DTYPE_BF16 && !Q_FP8;
   constexpr bool PV_F16 = PMODE == 2 && T16 == FI_DTYPE_BF16 && !Q_FP8;
@@ -312,23 +322,23 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   }
 
   // ---- logits scale (ref: variants.cuh:47-53; fp8: hopper/variants.cuh:74-76) ----
-  const bool soft_cap = p.logits_soft_cap > 0.f;
+  const bool soft_cap = f_cap;
   float qk_scale = p.sm_scale;
   if (p.scale_q) qk_scale *= p.scale_q[qo_head];
   if (p.scale_k) qk_scale *= p.scale_k[kv_head];
   const float c_log2 = qk_scale * kLog2e;
   const float inv_qk_scale = 1.0f / qk_scale;
   const float inv_cap = soft_cap ? 1.0f / p.logits_soft_cap : 0.f;
-  const float slope = p.use_alibi ? p.alibi_slopes[qo_head] : 0.f;
+  const float slope = f_alibi ? p.alibi_slopes[qo_head] : 0.f;
   const uint8_t* const mask_bits =
-      (GENERAL && p.custom_mask) ? p.custom_mask + (p.mask_indptr ? p.mask_indptr[req] : 0) : nullptr;
+      ((GEN & 4) && p.custom_mask) ? p.custom_mask + (p.mask_indptr ? p.mask_indptr[req] : 0) : nullptr;
   const uint64_t mask_row = (uint64_t)qo_idx * (uint64_t)kv_len;
   const uint64_t mask_bytes = ((uint64_t)qo_len * (uint64_t)kv_len + 7) >> 3;  // of this request
   // multi-item scoring: this row's item starts at q_pos - item_pos (ref: logits_mask_multi_item_scoring,
   // prefill.cuh:845-856: a query at p >= prefix_len sees kv_idx < prefix_len and kv_idx > p - token_pos[p - prefix])
   int mi_prefix = 0x7fffffff, mi_item_lo = 0;  // rows inside the prefix: plain causal
-  if constexpr (GENERAL) {
-    if (p.prefix_len_ptr) {
+  if constexpr ((GEN & 8) != 0) {
+    if (f_multi) {
       const int pl = (int)p.prefix_len_ptr[req];
       if (q_pos >= pl && q_pos < kv_len) {
         mi_prefix = pl;
@@ -526,7 +536,17 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
 
+  [[maybe_unused]] uint32_t mask_dw[3] = {~0u, ~0u, ~0u};
+  [[maybe_unused]] auto mask_fetch = [&](int t_rel) {
+    const uint64_t bit0 = mask_row + (uint64_t)((tile_base + t_rel) * kTileKV);
+    const uintptr_t a0 = ((uintptr_t)mask_bits + (bit0 >> 3)) & ~(uintptr_t)3;
+    const uintptr_t last = ((uintptr_t)mask_bits + mask_bytes - 1) & ~(uintptr_t)3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) mask_dw[i] = *(const uint32_t*)(a0 + 4 * i < last ? a0 + 4 * i : last);
+  };
   if (num_tiles > 0) {
+    if constexpr (GENERAL)
+      if (mask_bits) mask_fetch(0);
     // K rows are loaded TWO tiles ahead (during tile t the K rows of tile t+2 are in flight into kst; a tile
     // period is about one HBM round trip under load, the QK^T phase alone is not), V rows one tile ahead
     // (issued after QK^T, written to LDS before the closing barrier).  The row-offset table of tile t+3 is
@@ -575,7 +595,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
         for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
       {
         constexpr int NK = 2 * KSTEPS;
-        constexpr int PF = kQkPrefetch;
+        constexpr int PF = GENERAL ? 2 : kQkPrefetch;  // feature variants: two fragments fewer in flight (registers)
         u32x4 kf[NK];
         auto rd = [&](int i) {
           return *(const u32x4*)(kb + (i / KSTEPS) * 32 * ROWB + k_rd(i % KSTEPS));
@@ -609,37 +629,47 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
                              (p.window_left >= 0);
       if constexpr (GENERAL) {
         // custom mask: the 64 bits of this lane's query row for the tile's keys (bit qo_idx * kv_len + kv_idx,
-        // little-endian; ref: variants.cuh:80-86) are gathered from 9 bytes into two 32-bit windows, one
-        // per 32-key block.  Byte indices are clamped to the request's mask: bits past its end belong to no
-        // visible key.
+        // little-endian; ref: variants.cuh:80-86) sit in at most three aligned dwords; two 32-bit windows, one
+        // per 32-key block, are cut out of them.  Dword addresses are clamped to the request's mask: bits past
+        // its end belong to no visible key (an aligned dword never leaves the page of its first byte).
         uint32_t mask_win[2] = {~0u, ~0u};
         if (mask_bits) {
+          // mask_dw: the three aligned dwords around this row's 64 bits, fetched during the previous tile
           const uint64_t bit0 = mask_row + (uint64_t)tile0;
-          const uint64_t byte0 = bit0 >> 3;
-          const uint32_t sh = (uint32_t)(bit0 & 7);
-          uint32_t bytes[9];
-#pragma unroll
-          for (int i = 0; i < 9; ++i) bytes[i] = mask_bits[min(byte0 + i, mask_bytes - 1)];
-          const uint32_t w0 = bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | (bytes[3] << 24);
-          const uint32_t w1 = bytes[4] | (bytes[5] << 8) | (bytes[6] << 16) | (bytes[7] << 24);
-          mask_win[0] = __builtin_amdgcn_alignbit(w1, w0, sh);       // ({w1, w0} >> sh) & 0xffffffff
-          mask_win[1] = __builtin_amdgcn_alignbit(bytes[8], w1, sh);
+          const uint32_t sh = (uint32_t)((((uintptr_t)mask_bits + (bit0 >> 3)) & 3) * 8 + (bit0 & 7));
+          mask_win[0] = __builtin_amdgcn_alignbit(mask_dw[1], mask_dw[0], sh);  // ({dw1, dw0} >> sh) & 0xffffffff
+          mask_win[1] = __builtin_amdgcn_alignbit(mask_dw[2], mask_dw[1], sh);
         }
+        [[maybe_unused]] const float slope_c = slope * inv_qk_scale;
+        [[maybe_unused]] const float alibi_rel0 = (float)(tile0 + 4 * lh - qo_idx);
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int kv_idx = tile0 + 32 * kbk + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            [[maybe_unused]] const int kv_idx = tile0 + 32 * kbk + (r & 3) + 8 * (r >> 2) + 4 * lh;
             // ref: variants.cuh:67-76 -- alibi bias, then soft cap; kept in units of 1/c so that the
             // common exp2(fma(x, c, -m)) below applies
-            float lg = s_acc[kbk][r] * qk_scale;
-            if (p.use_alibi) lg += slope * (float)(kv_idx - qo_idx);
-            if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg * inv_cap);
-            lg *= inv_qk_scale;
-            if (mask_bits) lg = ((mask_win[kbk] >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1) ? lg : -INFINITY;
-            if (p.prefix_len_ptr) lg = (kv_idx < mi_prefix || kv_idx > mi_item_lo) ? lg : -INFINITY;
+            float lg = s_acc[kbk][r];
+            if constexpr (GEN == 1) {
+              // ALiBi alone: (s c + slope rel) / c = s + (slope / c) rel -- one FMA on a lane-constant base
+              lg = __builtin_fmaf(slope_c, alibi_rel0 + (float)(32 * kbk + (r & 3) + 8 * (r >> 2)), lg);
+            } else if constexpr ((GEN & 3) != 0) {
+              lg *= qk_scale;
+              if (f_alibi) lg += slope * (float)(kv_idx - qo_idx);
+              if (soft_cap) lg = p.logits_soft_cap * fast_tanh(lg * inv_cap);
+              lg *= inv_qk_scale;
+            }
+            if constexpr ((GEN & 4) != 0)
+              if (mask_bits) lg = ((mask_win[kbk] >> ((r & 3) + 8 * (r >> 2) + 4 * lh)) & 1) ? lg : -INFINITY;
+            if constexpr ((GEN & 8) != 0)
+              if (f_multi) lg = (kv_idx < mi_prefix || kv_idx > mi_item_lo) ? lg : -INFINITY;
             s_acc[kbk][r] = lg;
           }
+        // the next tile's mask dwords go out HERE: younger than the K / V loads this tile issued (which complete
+        // before the next tile's softmax anyway) and older than the ones the next tile issues, so the wait at
+        // their use leaves the K / V prefetch in flight.  (Fetched right before use -- 9 byte loads -- the wait
+        // drained the whole prefetch every tile: custom masks ran at 0.42 of the plain kernel's rate.)
+        if (mask_bits) mask_fetch(min(t + 1, num_tiles - 1));
       }
       if (need_mask) {
         // visible kv range of this lane's query: [vis_lo, vis_hi]; one unsigned compare per element
