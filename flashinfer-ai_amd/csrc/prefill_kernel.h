@@ -423,14 +423,29 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       }
     }
   };
-  // fused RoPE: frequencies of the 8 dims of this thread's chunk (dim i and i + D/2 share one)
-  float rope_freq[8];
+  // fused RoPE on K: this thread always stages the same 8 dims of rows RPP apart (pass to pass AND tile to tile),
+  // so cos / sin of its angles advance by a fixed rotation per pass -- an angle-addition recurrence (4 FMAs per
+  // dim) re-seeded with the hardware sin / cos every 8 tiles, instead of a range reduction + v_sin + v_cos per
+  // element.  The per-pass rotation depends on the chunk only and sits in LDS (16 registers otherwise); the sign
+  // of the sine term (- for the first half of the dims) is folded into the state.
+  __shared__ __attribute__((aligned(16))) float rope_step[ROPE ? CPR * 16 : 4];
+  [[maybe_unused]] float rope_c[ROPE ? 8 : 1], rope_s[ROPE ? 8 : 1];
+  [[maybe_unused]] auto rope_freq = [&](int e) {
+    const int i = (st_ch * 8 + e) % (D / 2);
+    return p.rope_rcp_scale * __powf(p.rope_rcp_theta, (float)(2 * i) / (float)D);
+  };
   if constexpr (ROPE) {
+    const float rope_sgn = (st_ch < CPR / 2) ? -1.f : 1.f;
+    if (st_row == 0) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int i = (st_ch * 8 + e) % (D / 2);
-      rope_freq[e] = p.rope_rcp_scale * __powf(p.rope_rcp_theta, (float)(2 * i) / (float)D);
+      for (int e = 0; e < 8; ++e) {
+        float sn, cs;
+        fast_sincos((float)RPP * rope_freq(e), &sn, &cs);
+        rope_step[st_ch * 16 + e] = cs;
+        rope_step[st_ch * 16 + 8 + e] = rope_sgn * sn;
+      }
     }
+    __syncthreads();  // before the first advance reads it (every thread of the workgroup gets here)
   }
   // swizzles (see header comment): K image for ds_read_b128, V image for ds_read_b64_tr_b16
   auto k_lds_off = [&](int row, int ch) -> int {
@@ -442,7 +457,8 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     const int g64 = (ch >> 2) ^ f;
     return row * ROWB + (g64 << 6) + ((ch & 3) << 4);
   };
-  auto write_k = [&](int tile, int buf, const Stage& st) {
+  // always_inline: called from two sites; outlined, its by-reference captures (the RoPE state) would live in scratch
+  auto write_k = [&](int tile, int buf, const Stage& st) __attribute__((always_inline)) {
     char* kb = lds_base + buf * 2 * TILE_BYTES;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
@@ -453,32 +469,54 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       if constexpr (ROPE) {
         // rotate K at its absolute position (ref: k_smem_inplace_apply_rotary, prefill.cuh:536-612).  The
         // partner chunk (dims +- D/2) sits CPR/2 lanes away: its packed registers are fetched with four
-        // cross-lane moves; sin / cos come from the hardware functions on a reduced angle, the eight
-        // frequencies of this thread's chunk are loop invariants (rope_freq).
-        const int kvi = tile * kTileKV + row;
+        // cross-lane moves.
+        // (the chunk index passes through an empty asm: what is derived from it -- the sign, the table address -- is
+        // recomputed here instead of occupying registers across the tile loop, where three of them spilled)
+        int sc = st_ch;
+        asm volatile("" : "+v"(sc));
+        if (ps == 0 && ((tile - tile_base) & 7) == 0) {
+          const float rope_sgn = (sc < CPR / 2) ? -1.f : 1.f;
+          const int kvi = tile * kTileKV + row;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float sn, cs;
+            fast_sincos((float)kvi * rope_freq(e), &sn, &cs);
+            rope_c[e] = cs;
+            rope_s[e] = rope_sgn * sn;
+          }
+        }
         u32x4 pw;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const uint32_t mine = kw[w];  // scalar copy first: bit_cast of a vector-element lvalue reads element 0
           pw[w] = __builtin_bit_cast(uint32_t, lane_xor<CPR / 2>(__builtin_bit_cast(float, mine)));
         }
-        const float sgn = (st_ch < CPR / 2) ? -1.f : 1.f;
         u32x4 outw;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          uint32_t res = 0;
+          float y[2];
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            float sn, cs;
-            fast_sincos((float)kvi * rope_freq[2 * w + e], &sn, &cs);
             const float x = M::to_f32((uint16_t)(kw[w] >> (16 * e)));
             const float partner = M::to_f32((uint16_t)(pw[w] >> (16 * e)));
-            const float y = __builtin_fmaf(sgn * partner, sn, x * cs);
-            res |= (uint32_t)M::from_f32(y) << (16 * e);
+            y[e] = __builtin_fmaf(partner, rope_s[2 * w + e], x * rope_c[2 * w + e]);
           }
-          outw[w] = res;
+          outw[w] = pack2<T16>(y[0], y[1]);
         }
         kw = outw;
+        // advance to the next pass (RPP rows on)
+        const float* const tab = rope_step + sc * 16;  // read here every pass (kept, the table costs 16 registers)
+#pragma unroll
+        for (int e4 = 0; e4 < 8; e4 += 4) {
+          const f32x4 dc4 = *(const f32x4*)(tab + e4), ds4 = *(const f32x4*)(tab + 8 + e4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float cn = rope_c[e4 + e] * dc4[e] - rope_s[e4 + e] * ds4[e];
+            const float sn = rope_s[e4 + e] * dc4[e] + rope_c[e4 + e] * ds4[e];
+            rope_c[e4 + e] = cn;
+            rope_s[e4 + e] = sn;
+          }
+        }
       }
       *(u32x4*)(kb + k_lds_off(row, st_ch)) = kw;
     }
@@ -595,7 +633,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
         for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
       {
         constexpr int NK = 2 * KSTEPS;
-        constexpr int PF = GENERAL ? 2 : kQkPrefetch;  // feature variants: two fragments fewer in flight (registers)
+        constexpr int PF = ROPE ? 1 : GENERAL ? 2 : kQkPrefetch;  // feature / RoPE variants: fewer fragments in flight (registers)
         u32x4 kf[NK];
         auto rd = [&](int i) {
           return *(const u32x4*)(kb + (i / KSTEPS) * 32 * ROWB + k_rd(i % KSTEPS));
