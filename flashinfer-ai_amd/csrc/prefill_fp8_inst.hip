@@ -6,36 +6,39 @@
 
 namespace fi {
 
-template <int OUT16>
+template <int OUT16, bool BF8>
 static hipError_t launch_v2(const PrefillKernelParams& p, int grid, hipStream_t stream) {
   // group sizes 1 / 2 / 4: one query head per wave, logit scale in a scalar register (see the kernel)
   const bool uni = p.group_size == 1 || p.group_size == 2 || p.group_size == 4;
   if (p.tile_q == 2 * kTileQ) {  // plan cut for 256-row q tiles: the 8-wave form
-    if (uni) batch_prefill_fp8_kernel<OUT16, true, 8><<<dim3(grid), dim3(512), 0, stream>>>(p);
-    else batch_prefill_fp8_kernel<OUT16, false, 8><<<dim3(grid), dim3(512), 0, stream>>>(p);
+    if (uni) batch_prefill_fp8_kernel<OUT16, true, 8, BF8><<<dim3(grid), dim3(512), 0, stream>>>(p);
+    else batch_prefill_fp8_kernel<OUT16, false, 8, BF8><<<dim3(grid), dim3(512), 0, stream>>>(p);
   } else {
-    if (uni) batch_prefill_fp8_kernel<OUT16, true, 4><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-    else batch_prefill_fp8_kernel<OUT16, false, 4><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    else batch_prefill_fp8_kernel<OUT16, false, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
   }
   return hipGetLastError();
 }
 
-hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, hipStream_t stream) {
+hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, int e5m2, hipStream_t stream) {
   const int grid = p.num_work * p.num_kv_heads;
   if (grid == 0) return hipSuccess;
   static const bool v1 = [] {
     const char* e = getenv("FI_PREFILL_FP8_V1");
     return e && atoi(e) != 0;
   }();
-  if (v1 && p.tile_q == kTileQ) {
+  if (v1 && p.tile_q == kTileQ && !e5m2) {
     if (out_dtype == FI_DTYPE_BF16)
       batch_prefill_fp8_v1_kernel<FI_DTYPE_BF16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
     else
       batch_prefill_fp8_v1_kernel<FI_DTYPE_F16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
     return hipGetLastError();
   }
-  return out_dtype == FI_DTYPE_BF16 ? launch_v2<FI_DTYPE_BF16>(p, grid, stream)
-                                    : launch_v2<FI_DTYPE_F16>(p, grid, stream);
+  if (e5m2)
+    return out_dtype == FI_DTYPE_BF16 ? launch_v2<FI_DTYPE_BF16, true>(p, grid, stream)
+                                      : launch_v2<FI_DTYPE_F16, true>(p, grid, stream);
+  return out_dtype == FI_DTYPE_BF16 ? launch_v2<FI_DTYPE_BF16, false>(p, grid, stream)
+                                    : launch_v2<FI_DTYPE_F16, false>(p, grid, stream);
 }
 
 }  // namespace fi

@@ -51,13 +51,28 @@ namespace fi {
 // one between two blocks of vector work.  What the compiler no longer does for these statements (guide 5.7): hazard
 // padding -- the leading s_nop covers a vector write of an operand right before the statement; every reader of a
 // result sits at least one MFMA (64 cycles) later in program order (noted at each use).
+// BF8: both operands e5m2 (cbsz / blgp = 1) instead of e4m3
+template <bool BF8>
 __device__ __forceinline__ void mfma_fp8_k64_asm(f32x16& c, const i32x8& a, const i32x8& b, int unit) {
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
-               : "+v"(c) : "v"(a), "v"(b), "v"(unit));
+  if constexpr (BF8)
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:1 blgp:1"
+                 : "+v"(c) : "v"(a), "v"(b), "v"(unit));
+  else
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0]"
+                 : "+v"(c) : "v"(a), "v"(b), "v"(unit));
 }
+template <bool BF8>
 __device__ __forceinline__ void mfma_fp8_k64_asm_zero(f32x16& c, const i32x8& a, const i32x8& b, int unit) {
-  asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
-               : "=v"(c) : "v"(a), "v"(b), "v"(unit));
+  if constexpr (BF8)
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0] cbsz:1 blgp:1"
+                 : "=v"(c) : "v"(a), "v"(b), "v"(unit));
+  else
+    asm volatile("s_nop 1\n\tv_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %3 op_sel_hi:[0,0,0]"
+                 : "=v"(c) : "v"(a), "v"(b), "v"(unit));
+}
+template <bool BF8>
+__device__ __forceinline__ f32x16 mfma_fp8_k64_fmt(i32x8 a, i32x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, BF8 ? 1 : 0, BF8 ? 1 : 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
 constexpr int kF8Stages = 4;        // ring depth (K and V each): tile t+1 / t read, t+2 landed, t+3 in flight
@@ -68,7 +83,8 @@ constexpr int kF8Ids = 1024;                             // page ids held in LDS
 constexpr int kF8IdsOff = kF8TabOff + 4 * kTileKV * 8;
 constexpr int kF8Smem = kF8IdsOff + kF8Ids * 4;          // 71 680 B: two workgroups per CU
 constexpr float kF8Thr = 3.0f;                           // log2 headroom of the deferred rescale
-constexpr float kF8Log2Scale = 8.807354922057604f - kF8Thr;  // log2(448) - headroom
+constexpr float kF8Log2Scale = 8.807354922057604f - kF8Thr;   // log2(448) - headroom    (e4m3)
+constexpr float kBF8Log2Scale = 15.807354922057604f - kF8Thr;  // log2(57344) - headroom  (e5m2)
 
 // transposed 8-bit LDS read, issued from an asm statement: as an intrinsic the compiler cannot tell it from the
 // LDS-DMA targets and drains vmcnt in front of it.  Its completion is awaited by hand (counted lgkmcnt; LDS
@@ -91,11 +107,14 @@ typedef const __attribute__((address_space(1))) void f8_gbl_void;
 // NW: waves per workgroup.  4: 128 packed query rows, two workgroups per CU.  8 (plans cut with cta_tile_q = 256):
 // 256 rows share every K/V tile, so a wave issues two LDS-DMA pieces per 64-key step instead of four and the
 // page-id / row-offset tables are built once per 256 rows; one workgroup per CU, the same 8 waves.
-template <int OUT16, bool UNI, int NW>
+// BF8: q, k, v e5m2 -- P is scaled by 57344 / 2^kF8Thr and rounded to e5m2 (ref: hopper/variants.cuh:71-73)
+template <int OUT16, bool UNI, int NW, bool BF8>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
   constexpr int D = 128;
   constexpr int kThreads = NW * 64;
   constexpr int kTQ = NW * 32;  // packed query rows per workgroup
+  constexpr float kLog2Scale = BF8 ? kBF8Log2Scale : kF8Log2Scale;
+  constexpr float kPMax = BF8 ? 57344.f : 448.f;  // largest value of the type P is rounded to
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int DBLK = D / 32;
   // ONE static array for every LDS object: the compiler separates an LDS-DMA target from an LDS read by
@@ -241,7 +260,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
-  float m_adj = m_run - kF8Log2Scale;  // exp2 argument offset: P x 448 / 2^kF8Thr = 2^(c s - m_adj)
+  float m_adj = m_run - kLog2Scale;  // exp2 argument offset: P x 448 / 2^kF8Thr = 2^(c s - m_adj)
 
   if (num_tiles > 0) {
     // ---- page ids of this kv range -> LDS (refilled when the walk leaves the window) ----
@@ -340,7 +359,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     auto rescale_to = [&](float m_true) {
       const float alpha = fast_exp2(m_run - m_true);
       m_run = m_true;
-      m_adj = m_true - kF8Log2Scale;
+      m_adj = m_true - kLog2Scale;
       l_run *= alpha;
       // whole-vector statements, no loop: in a block the compiler treats as cold a loop may stay rolled, and a
       // runtime index would push the accumulators into scratch memory for the whole kernel
@@ -375,16 +394,21 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       int u0, u1;  // volatile: identical empty statements would otherwise be merged into one value (and copied)
       asm volatile("" : "=v"(u0));
       asm volatile("" : "=v"(u1));
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], u0, false), true);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], u1, false), true);
+      if constexpr (BF8) {
+        w0 = __builtin_amdgcn_cvt_pk_bf8_f32(x[2], x[3], __builtin_amdgcn_cvt_pk_bf8_f32(x[0], x[1], u0, false), true);
+        w1 = __builtin_amdgcn_cvt_pk_bf8_f32(x[6], x[7], __builtin_amdgcn_cvt_pk_bf8_f32(x[4], x[5], u1, false), true);
+      } else {
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], u0, false), true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6], x[7], __builtin_amdgcn_cvt_pk_fp8_f32(x[4], x[5], u1, false), true);
+      }
     };
 
     // ---- prologue: S^T of tile 0, its mask and row maximum ----
     f32x16 s_a[2], s_b[2];
     {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      s_a[0] = mfma_fp8_k64(k_frag(smem, 1), q1, mfma_fp8_k64(k_frag(smem, 0), q0, zero));
-      s_a[1] = mfma_fp8_k64(k_frag(smem, 3), q1, mfma_fp8_k64(k_frag(smem, 2), q0, zero));
+      s_a[0] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 1), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 0), q0, zero));
+      s_a[1] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 3), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 2), q0, zero));
       if (tile_needs_mask(0)) apply_mask(0, s_a);
     }
 
@@ -433,13 +457,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       int unit = 0x7F7F7F7F;
       asm volatile("" : "+v"(unit));
 #if FI_PF8_ASM_MFMA
-#define FI_F8_QK0(dst, a, b) if (!(FI_PF8_KO & 16)) mfma_fp8_k64_asm_zero(dst, a, b, unit)
-#define FI_F8_QK1(dst, a, b) if (!(FI_PF8_KO & 16)) mfma_fp8_k64_asm(dst, a, b, unit)
-#define FI_F8_PV(dst, a, b) if (!(FI_PF8_KO & 8)) mfma_fp8_k64_asm(dst, a, b, unit)
+#define FI_F8_QK0(dst, a, b) if (!(FI_PF8_KO & 16)) mfma_fp8_k64_asm_zero<BF8>(dst, a, b, unit)
+#define FI_F8_QK1(dst, a, b) if (!(FI_PF8_KO & 16)) mfma_fp8_k64_asm<BF8>(dst, a, b, unit)
+#define FI_F8_PV(dst, a, b) if (!(FI_PF8_KO & 8)) mfma_fp8_k64_asm<BF8>(dst, a, b, unit)
 #else
-#define FI_F8_QK0(dst, a, b) if (!(FI_PF8_KO & 16)) dst = mfma_fp8_k64(a, b, zero)
-#define FI_F8_QK1(dst, a, b) if (!(FI_PF8_KO & 16)) dst = mfma_fp8_k64(a, b, dst)
-#define FI_F8_PV(dst, a, b) if (!(FI_PF8_KO & 8)) dst = mfma_fp8_k64(a, b, dst)
+#define FI_F8_QK0(dst, a, b) if (!(FI_PF8_KO & 16)) dst = mfma_fp8_k64_fmt<BF8>(a, b, zero)
+#define FI_F8_QK1(dst, a, b) if (!(FI_PF8_KO & 16)) dst = mfma_fp8_k64_fmt<BF8>(a, b, dst)
+#define FI_F8_PV(dst, a, b) if (!(FI_PF8_KO & 8)) dst = mfma_fp8_k64_fmt<BF8>(a, b, dst)
 #endif
       i32x8 kf0 = k_frag(kb, 0);
       i32x8 kf1 = k_frag(kb, 1);
@@ -463,7 +487,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       FI_F8_QK1(sn[1], kf1, q1);
       if (FI_PF8_KO & 16) asm volatile("" : "+v"(kf0), "+v"(kf1));
       __builtin_amdgcn_sched_barrier(0);
-      if (__builtin_expect(!(FI_PF8_KO & 32) && __any(!(fmaxf(fmaxf(cs0, cs1), fmaxf(cs2, cs3)) <= 448.f)), 0)) {
+      if (__builtin_expect(!(FI_PF8_KO & 32) && __any(!(fmaxf(fmaxf(cs0, cs1), fmaxf(cs2, cs3)) <= kPMax)), 0)) {
         // rare: some probability may have left the e4m3 range -- exact maximum of tile t, move the exponent, again
         rescale_to(fmaxf(m_run, row_max(sc) * c_exp));
         exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
@@ -550,7 +574,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
   const bool empty = !(l_run > 0.f);
   float inv = empty ? 0.f : 1.0f / l_run;
   if (p.scale_v) inv *= p.scale_v[kv_head];
-  const float lse_val = empty ? FI_NEG_INF : m_run + fast_log2(l_run) - kF8Log2Scale;
+  const float lse_val = empty ? FI_NEG_INF : m_run + fast_log2(l_run) - kLog2Scale;
   if (split) {
     if (row_valid) {
       const int64_t entry = p.merge_indptr ? (int64_t)p.merge_indptr[qo_start + qo_idx] + kv_chunk

@@ -235,7 +235,8 @@ def test_prefill_cuda_graph_mode_and_errors():
         w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, custom_mask=torch.ones(4, dtype=torch.bool))
 
 
-def test_fp8_native_kernel_matches_upcast_kernel():
+@pytest.mark.parametrize("f8", [torch.float8_e4m3fn, torch.float8_e5m2])
+def test_fp8_native_kernel_matches_upcast_kernel(f8):
     """The fp8-native kernel (MX-scaled MFMA, transposed V image) and the upcast-to-bf16 kernel implement
     the same arithmetic with the same 64-row tiles, so they must agree far tighter than the fp8 bar:
     a sliding window wider than the sequence selects the upcast kernel without changing the result."""
@@ -245,12 +246,12 @@ def test_fp8_native_kernel_matches_upcast_kernel():
     kv_lens, qo_lens = [700, 130], [300, 130]
     torch.manual_seed(3)
     cache16 = [torch.randn(-(-l // ps), 2, ps, hkv, d) for l in kv_lens]
-    cache = torch.cat(cache16).to(torch.float8_e4m3fn)
+    cache = torch.cat(cache16).to(f8)
     pages = [c.shape[0] for c in cache16]
     indptr = torch.tensor([0] + list(torch.tensor(pages).cumsum(0)), dtype=torch.int32)
     indices = torch.arange(sum(pages), dtype=torch.int32)
     last = torch.tensor([(l - 1) % ps + 1 for l in kv_lens], dtype=torch.int32)
-    q8 = torch.randn(sum(qo_lens), hq, d).to(torch.float8_e4m3fn)
+    q8 = torch.randn(sum(qo_lens), hq, d).to(f8)
     qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
     sq, sk, sv = torch.rand(hq) + 0.5, torch.rand(hkv) + 0.5, torch.rand(hkv) + 0.5
     outs = []
@@ -258,7 +259,7 @@ def test_fp8_native_kernel_matches_upcast_kernel():
         ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
         w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, "NHD")
         w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps, causal=True,
-               window_left=window, q_data_type=torch.float8_e4m3fn, kv_data_type=torch.float8_e4m3fn,
+               window_left=window, q_data_type=f8, kv_data_type=f8,
                o_data_type=torch.float16)
         outs.append(w.run(q8.to(DEV), cache.to(DEV), return_lse=True, scale_q=sq.to(DEV), scale_k=sk.to(DEV),
                           scale_v=sv.to(DEV)))
@@ -269,8 +270,12 @@ def test_fp8_native_kernel_matches_upcast_kernel():
     # the stale maximum -- each probability lands on a slightly different 3-bit grid than with the upcast kernel's
     # x448 against the running maximum; differences at the level of the e4m3 rounding itself, far inside the
     # 5e-2 bar.  The lse comes from the unrounded probabilities and agrees to f32 rounding.)
+    # e5m2 (2-bit significand of P): the same statement one octave coarser
     diff = (outs[0][0].float() - outs[1][0].float()).abs()
-    assert diff.max() < 5e-2 and diff.mean() < 2e-3
+    if f8 == torch.float8_e4m3fn:
+        assert diff.max() < 5e-2 and diff.mean() < 2e-3
+    else:
+        assert diff.max() < 1e-1 and diff.mean() < 5e-3
     torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-4, atol=1e-4)
 
 
