@@ -24,7 +24,7 @@ FI_PF_DECL_D(0, 2, 2) FI_PF_DECL_D(1, 2, 2) FI_PF_DECL_D(0, 3, 3) FI_PF_DECL_D(1
 #undef FI_PF_DECL
 #undef FI_PF_DECL_D
 
-hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, int e5m2, hipStream_t stream);
+hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, int e5m2, int head_dim, hipStream_t stream);
 
 // fp8-native kernel (MX-scaled MFMA for both contractions): e4m3 or e5m2 q/k/v, head_dim 128, plain logits, no fused
 // RoPE, no sliding window.  FI_PREFILL_FP8_NATIVE=0 forces the
@@ -34,7 +34,12 @@ static bool use_fp8_native(const PrefillKernelParams& kp, int q_dt, int kv_dt, i
     const char* e = getenv("FI_PREFILL_FP8_NATIVE");
     return e ? atoi(e) != 0 : true;
   }();
-  return enabled && (q_dt == FI_DTYPE_FP8_E4M3 || q_dt == FI_DTYPE_FP8_E5M2) && kv_dt == q_dt && head_dim == 128 &&
+  static const bool d64 = [] {
+    const char* e = getenv("FI_PREFILL_FP8_NATIVE_D64");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return enabled && (q_dt == FI_DTYPE_FP8_E4M3 || q_dt == FI_DTYPE_FP8_E5M2) && kv_dt == q_dt &&
+         (head_dim == 128 || (head_dim == 64 && d64 && kp.tile_q == kTileQ)) &&
          !rope && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
          kp.window_left < 0 && !kp.custom_mask;
 }
@@ -390,7 +395,7 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
              "the fp8-native kernel runs: fp8 q/k/v of one type, head_dim 128, no RoPE / ALiBi / soft cap / window / mask",
              kp.tile_q);
   if (fp8_native) {
-    FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, a->q_dtype == FI_DTYPE_FP8_E5M2, stream));
+    FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, a->q_dtype == FI_DTYPE_FP8_E5M2, kv.head_dim, stream));
   } else {
     FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
   }
@@ -500,7 +505,7 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
     }
   }
   if (use_fp8_native(kp, a->q_dtype, a->kv_dtype, a->head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA)) {
-    FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, a->q_dtype == FI_DTYPE_FP8_E5M2, stream));
+    FI_HIP_CALL(prefill_fp8_launch(kp, a->o_dtype, a->q_dtype == FI_DTYPE_FP8_E5M2, a->head_dim, stream));
   } else {
     FI_HIP_CALL(fn(kp, a->pos_encoding_mode == FI_POS_ROPE_LLAMA, stream));
   }

@@ -108,9 +108,16 @@ typedef const __attribute__((address_space(1))) void f8_gbl_void;
 // 256 rows share every K/V tile, so a wave issues two LDS-DMA pieces per 64-key step instead of four and the
 // page-id / row-offset tables are built once per 256 rows; one workgroup per CU, the same 8 waves.
 // BF8: q, k, v e5m2 -- P is scaled by 57344 / 2^kF8Thr and rounded to e5m2 (ref: hopper/variants.cuh:71-73)
-template <int OUT16, bool UNI, int NW, bool BF8>
+// D: head_dim 128, or 64 (NW = 4 only): rows of 64 bytes in the same ring (a stage keeps its 8 KB stride), one k step
+// per QK^T block and two P.V blocks -- two MFMAs each per 64-key step against the same softmax work, so that form is
+// vector-bound by construction and its step is written plainly (builtin MFMAs, no hand interleave).
+template <int OUT16, bool UNI, int NW, bool BF8, int D = 128>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
-  constexpr int D = 128;
+  static_assert(D == 128 || (D == 64 && NW == 4), "head_dim 128, or 64 with four waves");
+  constexpr int ROWB = D;             // bytes per K / V row in LDS
+  constexpr int SLOTS = ROWB / 16;    // 16-byte slots per row
+  constexpr int KBLK = 32 * ROWB;     // byte offset of the second 32-row block of a tile
+  constexpr int TRR = 16 * ROWB;      // row step of the four transposed V reads
   constexpr int kThreads = NW * 64;
   constexpr int kTQ = NW * 32;  // packed query rows per workgroup
   constexpr float kLog2Scale = BF8 ? kBF8Log2Scale : kF8Log2Scale;
@@ -180,12 +187,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
   const int q_pos = kv_len - qo_len + qo_idx;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q, h) holds bytes [64 kk + 32 h, +32) of its row ----
+  constexpr int KK = D / 64;  // k steps of QK^T
   i32x8 qf[2];
+  qf[1] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
   {
     const uint8_t* qrow = (const uint8_t*)p.q + (int64_t)(qo_start + qo_idx) * p.q_stride_n +
                           (int64_t)qo_head * p.q_stride_h;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
       const u32x4 lo = *(const u32x4*)(qrow + 64 * kk + 32 * lh);
       const u32x4 hi = *(const u32x4*)(qrow + 64 * kk + 32 * lh + 16);
       qf[kk] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
@@ -226,9 +235,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
 
   // ---- lane constants of the LDS images (same swizzles as the first structure) ----
   // DMA: thread -> (row = tid / 8 [+ 32], 16-byte slot tid % 8); the slot receives global chunk slot ^ swizzle(row)
-  const int st_row = tid >> 3, st_slot = tid & 7;
-  const int kc = (st_slot ^ ((st_row >> 1) & 7)) << 4;
-  const int vc = (st_slot ^ ((((st_row >> 1) & 1) << 1) | (((st_row >> 3) & 1) << 2))) << 4;
+  // (D = 64: four slots per row, a piece is 16 rows, 256 threads cover the 64 rows in one pass; K rows are
+  // swizzled by (row >> 2) & 3 -- the 16 rows one ds_read_b128 lane group touches then fill 256 bytes of banks -- and
+  // V rows by bit 3 of the row on slot bit 1, which does the same for the 8 rows x 32 bytes of a transposed read)
+  const int st_row = tid / SLOTS, st_slot = tid % SLOTS;
+  const int kc = (D == 128 ? (st_slot ^ ((st_row >> 1) & 7)) : (st_slot ^ ((st_row >> 2) & 3))) << 4;
+  const int vc = (D == 128 ? (st_slot ^ ((((st_row >> 1) & 1) << 1) | (((st_row >> 3) & 1) << 2)))
+                           : (st_slot ^ (((st_row >> 3) & 1) << 1))) << 4;
   const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
   const char* const k_thr = (const char*)p.k + head_off + kc;
   const char* const v_thr = (const char*)p.v + head_off + vc;
@@ -238,25 +251,27 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
 #pragma unroll
   for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int e = 0; e < 2; ++e) k_rd[kk][e] = lq * 128 + (((4 * kk + 2 * lh + e) ^ ((lq >> 1) & 7)) << 4);
+    for (int e = 0; e < 2; ++e)
+      k_rd[kk][e] = D == 128 ? lq * 128 + (((4 * kk + 2 * lh + e) ^ ((lq >> 1) & 7)) << 4)
+                             : lq * 64 + (((2 * lh + e) ^ ((lq >> 2) & 3)) << 4);
   // V^T fragment: see prefill_fp8_v1_kernel.h (transposed 8-bit read; lane i of a 16-lane group addresses row
   // b = i >> 1, bytes 8 (i & 1) .. +8 of chunk 2 db + g)
-  int v_rd[DBLK];
+  int v_rd[4];  // [db]; head_dim 64 uses the first two
   {
     const int i16 = lane & 15, g = (lane >> 4) & 1, b = i16 >> 1;
     const int row = 4 * lh + (b & 3) + 8 * (b >> 2);
-    const int sw = (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
-    const int base = row * 128 + ((g ^ sw) << 4) + 8 * (i16 & 1);
+    const int sw = D == 128 ? (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2) : ((row >> 3) & 1) << 1;
+    const int base = row * ROWB + ((g ^ sw) << 4) + 8 * (i16 & 1);
 #pragma unroll
-    for (int db = 0; db < DBLK; ++db) v_rd[db] = base ^ (db << 5);  // ring / stage / row-block offsets: immediates
+    for (int db = 0; db < 4; ++db) v_rd[db] = base ^ ((db & (DBLK - 1)) << 5);  // ring / stage / row-block offsets: immediates
   }
   uint64_t* const tab = (uint64_t*)(smem + kF8TabOff);
   int32_t* const ids = (int32_t*)(smem + kF8IdsOff);
 
   // ---- running state ----
-  f32x16 o_acc[DBLK];
+  f32x16 o_acc[4];  // [db]; head_dim 64 uses the first two (the others are dead and cost nothing)
 #pragma unroll
-  for (int db = 0; db < DBLK; ++db)
+  for (int db = 0; db < 4; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
@@ -294,16 +309,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     // the table read does not sit at the top of the step
     auto dma_offsets = [&](int slot, uint64_t& off0, uint64_t& off1) {
       off0 = tab[slot * kTileKV + st_row];  // NW == 8: st_row covers all 64 rows, one K and one V piece per wave
-      off1 = NW == 4 ? tab[slot * kTileKV + st_row + 32] : 0;
+      off1 = (NW == 4 && D == 128) ? tab[slot * kTileKV + st_row + 32] : 0;
     };
     auto dma_issue = [&](int stage, uint64_t off0, uint64_t off1) {
       char* const kdst = smem + stage * kF8KTile + wave * 1024;
       char* const vdst = kdst + kF8VOff;
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off0), (f8_lds_void*)(kdst), 16, 0, 0);
-      if constexpr (NW == 4)
+      if constexpr (NW == 4 && D == 128)
         __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off1), (f8_lds_void*)(kdst + 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off0), (f8_lds_void*)(vdst), 16, 0, 0);
-      if constexpr (NW == 4)
+      if constexpr (NW == 4 && D == 128)
         __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off1), (f8_lds_void*)(vdst + 4096), 16, 0, 0);
     };
     auto dma_tile = [&](int slot, int stage) {
@@ -321,14 +336,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     dma_tile(2, 2);
     // tiles 0 and 1 have landed (tile 2: this wave's 4 (NW = 8: 2) pieces in flight); wait + barrier as one
     // statement (see the step)
-    if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    constexpr bool kFourPieces = NW == 4 && D == 128;  // LDS-DMA pieces per wave and tile: 4, else 2
+    if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
 
     // ---- building blocks ----
     const i32x8 q0 = qf[0], q1 = qf[1];
     auto k_frag = [&](const char* kb, int i) {  // fragment i = 2 kbk + kk of the K tile at kb
-      const u32x4 lo = *(const u32x4*)(kb + (i >> 1) * 4096 + k_rd[i & 1][0]);
-      const u32x4 hi = *(const u32x4*)(kb + (i >> 1) * 4096 + k_rd[i & 1][1]);
+      const u32x4 lo = *(const u32x4*)(kb + (i >> 1) * KBLK + k_rd[i & 1][0]);
+      const u32x4 hi = *(const u32x4*)(kb + (i >> 1) * KBLK + k_rd[i & 1][1]);
       return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
     };
     auto apply_mask = [&](int t_rel, f32x16 (&s)[2]) {
@@ -365,8 +381,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       // runtime index would push the accumulators into scratch memory for the whole kernel
       o_acc[0] = o_acc[0] * alpha;
       o_acc[1] = o_acc[1] * alpha;
-      o_acc[2] = o_acc[2] * alpha;
-      o_acc[3] = o_acc[3] * alpha;
+      if constexpr (D == 128) {
+        o_acc[2] = o_acc[2] * alpha;
+        o_acc[3] = o_acc[3] * alpha;
+      }
     };
     const float c_exp = UNI ? c_uni : c_lane;
     // exp2 argument c s - m_adj.  UNI: c from a SCALAR register, so the instruction reads two vector registers
@@ -407,8 +425,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     f32x16 s_a[2], s_b[2];
     {
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      s_a[0] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 1), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 0), q0, zero));
-      s_a[1] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 3), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 2), q0, zero));
+      if constexpr (D == 128) {
+        s_a[0] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 1), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 0), q0, zero));
+        s_a[1] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 3), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 2), q0, zero));
+      } else {
+        s_a[0] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 0), q0, zero);
+        s_a[1] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 2), q0, zero);
+      }
       if (tile_needs_mask(0)) apply_mask(0, s_a);
     }
 
@@ -422,6 +445,55 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       constexpr bool MASK = decltype(mask_c)::value;
       // table of tile t+4 -> the slot tile t's table used (read for the last time at step t-3)
       if (wave == ST) make_tab(t + 4, ST);
+      if constexpr (D == 64) {
+        // head_dim 64: the same step, plainly written -- two QK^T MFMAs (one k step), two P.V MFMAs
+        uint64_t off0, off1;
+        dma_offsets((ST + 3) & 3, off0, off1);
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const char* const kb = smem + ((ST + 1) & 3) * kF8KTile;
+        constexpr int VB = kF8VOff + ST * kF8KTile;
+        i32x2 va[4], vb[4];
+        va[0] = lds_tr8<VB + 0 * TRR>(v_rd[0]);
+        va[1] = lds_tr8<VB + 1 * TRR>(v_rd[0]);
+        va[2] = lds_tr8<VB + 2 * TRR>(v_rd[0]);
+        va[3] = lds_tr8<VB + 3 * TRR>(v_rd[0]);
+        vb[0] = lds_tr8<VB + 0 * TRR>(v_rd[1]);
+        vb[1] = lds_tr8<VB + 1 * TRR>(v_rd[1]);
+        vb[2] = lds_tr8<VB + 2 * TRR>(v_rd[1]);
+        vb[3] = lds_tr8<VB + 3 * TRR>(v_rd[1]);
+        const i32x8 kf0 = k_frag(kb, 0), kf1 = k_frag(kb, 2);
+        int p8w[8];
+        float cs0, cs1, cs2, cs3;
+        __builtin_amdgcn_sched_barrier(0);
+        exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
+        dma_issue((ST + 3) & 3, off0, off1);
+        __builtin_amdgcn_sched_barrier(0);
+        sn[0] = mfma_fp8_k64_fmt<BF8>(kf0, q0, zero);
+        exp_chunk(sc[0], 8, p8w[2], p8w[3], cs1);
+        __builtin_amdgcn_sched_barrier(0);
+        sn[1] = mfma_fp8_k64_fmt<BF8>(kf1, q0, zero);
+        exp_chunk(sc[1], 0, p8w[4], p8w[5], cs2);
+        exp_chunk(sc[1], 8, p8w[6], p8w[7], cs3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_expect(__any(!(fmaxf(fmaxf(cs0, cs1), fmaxf(cs2, cs3)) <= kPMax)), 0)) {
+          rescale_to(fmaxf(m_run, row_max(sc) * c_exp));
+          exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
+          exp_chunk(sc[0], 8, p8w[2], p8w[3], cs1);
+          exp_chunk(sc[1], 0, p8w[4], p8w[5], cs2);
+          exp_chunk(sc[1], 8, p8w[6], p8w[7], cs3);
+        }
+        l_run += (cs0 + cs1) + (cs2 + cs3);
+        const i32x8 p8 = {p8w[0], p8w[1], p8w[2], p8w[3], p8w[4], p8w[5], p8w[6], p8w[7]};
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+        o_acc[0] = mfma_fp8_k64_fmt<BF8>(i32x8{va[0][0], va[0][1], va[1][0], va[1][1], va[2][0], va[2][1], va[3][0], va[3][1]},
+                                         p8, o_acc[0]);
+        o_acc[1] = mfma_fp8_k64_fmt<BF8>(i32x8{vb[0][0], vb[0][1], vb[1][0], vb[1][1], vb[2][0], vb[2][1], vb[3][0], vb[3][1]},
+                                         p8, o_acc[1]);
+        if constexpr (MASK) apply_mask(t + 1, sn);
+        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        return;
+      }
       // row offsets of tile t+3 (its DMA is issued inside region A, after the table read has returned)
       uint64_t off0, off1;
       dma_offsets((ST + 3) & 3, off0, off1);
@@ -434,10 +506,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       constexpr int VB = kF8VOff + ST * kF8KTile;  // V tile of stage ST; transposed reads r = 0..3 at rows 0 / 16 / 32 / 48
       i32x2 va[4], vb[4];
 #define FI_F8_VREAD(dst, db)                        \
-  dst[0] = lds_tr8<VB + 0 * 2048>(v_rd[db]);        \
-  dst[1] = lds_tr8<VB + 1 * 2048>(v_rd[db]);        \
-  dst[2] = lds_tr8<VB + 2 * 2048>(v_rd[db]);        \
-  dst[3] = lds_tr8<VB + 3 * 2048>(v_rd[db]);
+  dst[0] = lds_tr8<VB + 0 * TRR>(v_rd[db]);        \
+  dst[1] = lds_tr8<VB + 1 * TRR>(v_rd[db]);        \
+  dst[2] = lds_tr8<VB + 2 * TRR>(v_rd[db]);        \
+  dst[3] = lds_tr8<VB + 3 * TRR>(v_rd[db]);
 #define FI_F8_VWAIT(n, w) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]))
 #define FI_F8_VFRAG(w) (i32x8{w[0][0], w[0][1], w[1][0], w[1][1], w[2][0], w[2][1], w[3][0], w[3][1]})
       FI_F8_VREAD(va, 0)
@@ -524,7 +596,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       // which would hoist the next step's LDS reads between the wait and the barrier.
       // (in flight afterwards: V of tile t+2 and both operands of tile t+3 -- 6 pieces, 3 with NW = 8)
       if (!(FI_PF8_KO & 4)) {
-        if constexpr (NW == 4) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     };
@@ -607,15 +679,17 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       for (int r4 = 0; r4 < 4; ++r4) {
         const uint32_t w0 = pack2<OUT16>(o_acc[db][4 * r4 + 0] * inv, o_acc[db][4 * r4 + 1] * inv);
         const uint32_t w1 = pack2<OUT16>(o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv);
-        *(u32x2*)(region + lq * 256 + (((4 * db + r4) ^ (lq & 15)) << 4) + 8 * lh) = u32x2{w0, w1};
+        *(u32x2*)(region + lq * (2 * D) + (((4 * db + r4) ^ (lq & (D / 8 - 1))) << 4) + 8 * lh) = u32x2{w0, w1};
       }
     }
     __builtin_amdgcn_wave_barrier();  // LDS operations of one wave execute in order
-    const int rr = lane >> 4, ch = lane & 15;
+    constexpr int CPRO = D / 8;        // 16-byte chunks per output row
+    constexpr int RPS = 64 / CPRO;     // rows per store instruction
+    const int rr = lane / CPRO, ch = lane % CPRO;
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int row = 4 * ps + rr;
-      const u32x4 w = *(const u32x4*)(region + row * 256 + ((ch ^ (row & 15)) << 4));
+    for (int ps = 0; ps < 32 / RPS; ++ps) {
+      const int row = RPS * ps + rr;
+      const u32x4 w = *(const u32x4*)(region + row * (2 * D) + ((ch ^ (row & (CPRO - 1))) << 4));
       const int64_t ob = rowtab[row];
       if (ob >= 0) *(u32x4*)((uint16_t*)p.o + ob + 8 * ch) = w;
     }

@@ -113,7 +113,8 @@ def test_batch_prefill_fp8_kv_cache(kv_dtype):
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("seq_len", [117, 509])
-def test_single_prefill_fp8_qkv(causal, seq_len):
+@pytest.mark.parametrize("d", [128, 64])
+def test_single_prefill_fp8_qkv(causal, seq_len, d):
     """fp8 q/k/v with per-head scales.  Two bars: (1) against the oracle that restates the reference's
     fp8 arithmetic (P rounded to e4m3, 3-bit significand) -- rtol = atol = 5e-2: the e4m3 rounding of P is
     taken relative to the RUNNING row maximum of the online softmax (in the reference too, with its own
@@ -123,7 +124,7 @@ def test_single_prefill_fp8_qkv(causal, seq_len):
     import flashinfer
 
     torch.manual_seed(2)
-    h, d = 8, 128
+    h = 8
     q, k, v = (torch.randn(seq_len, h, d).half() for _ in range(3))
     q8, sq = R.per_head_symmetric_quant(q)
     k8, sk = R.per_head_symmetric_quant(k)
@@ -236,13 +237,14 @@ def test_prefill_cuda_graph_mode_and_errors():
 
 
 @pytest.mark.parametrize("f8", [torch.float8_e4m3fn, torch.float8_e5m2])
-def test_fp8_native_kernel_matches_upcast_kernel(f8):
+@pytest.mark.parametrize("d", [128, 64])
+def test_fp8_native_kernel_matches_upcast_kernel(f8, d):
     """The fp8-native kernel (MX-scaled MFMA, transposed V image) and the upcast-to-bf16 kernel implement
     the same arithmetic with the same 64-row tiles, so they must agree far tighter than the fp8 bar:
     a sliding window wider than the sequence selects the upcast kernel without changing the result."""
     import flashinfer
 
-    hq, hkv, d, ps = 16, 4, 128, 16
+    hq, hkv, ps = 16, 4, 16
     kv_lens, qo_lens = [700, 130], [300, 130]
     torch.manual_seed(3)
     cache16 = [torch.randn(-(-l // ps), 2, ps, hkv, d) for l in kv_lens]
