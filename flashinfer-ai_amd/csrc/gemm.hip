@@ -781,9 +781,11 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
         for (int r = 0; r < 16; ++r) acc[i2][j2][r] = 0.f;
     // D(0) landed.  The output stores are younger than both blocks and vmcnt retires in order, so with
     // stores in the queue the only count that is sure to cover D(0) is 0.
-    if (kblocks > 1 && !stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // also: every wave is done with the stage 2 scratch before step 0's DMA
+    // wait + barrier as ONE asm statement: the s_barrier builtin is no memory fence for the compiler, which may
+    // hoist the next LDS reads between a separate wait and the barrier (seen in prefill_fp8_kernel.h)
+    // (also: every wave is done with the stage 2 scratch before step 0's DMA)
+    if (kblocks > 1 && !stored) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     f32x16g p_carry;  // block (1, 1) of the previous k step, folded at the start of the next one
 #pragma unroll
     for (int r = 0; r < 16; ++r) p_carry[r] = 0.f;
@@ -861,9 +863,8 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
       p_carry = p11;
       s_carry = s1;
       // D(kb + 1) must have landed (all waves' pieces: barrier); the 8 pieces of D(kb + 2) stay in flight
-      if (kb + 2 < kblocks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      if (kb + 2 < kblocks) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);  // no mixing of two k steps either
     };
     {
