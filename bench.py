@@ -178,8 +178,19 @@ def secondary_workloads(device):
     # C3: fp8_e4m3 causal, qo_len 2048, kv_len 8192, bs 16, head_dim 128 (32/8 heads as C2), page 16
     b, qo, kv, hq, hkv, d, ps = 16, 2048, 8192, 32, 8, 128, 16
     npages = b * kv // ps
-    cache = torch.randn(npages, 2, ps, hkv, d, device=device, dtype=torch.bfloat16, generator=g).to(torch.float8_e4m3fn)
-    q = torch.randn(b * qo, hq, d, device=device, dtype=torch.bfloat16, generator=g).to(torch.float8_e4m3fn)
+    # 16-bit randn q / cache -> per-head symmetric quantisation to e4m3, scale = amax / 448 (clamp 1e-6),
+    # the reference's helper restated (tests/attention/test_hopper_fp8_attention.py:12-41); the scales go to run()
+    def quant_per_head(x, head_axis):
+        dims = [i for i in range(x.dim()) if i != head_axis]
+        scale = (x.float().abs().amax(dim=dims, keepdim=True) / 448.0).clamp(min=1e-6)
+        return (x.float() / scale).to(torch.float8_e4m3fn), scale.flatten().contiguous()
+
+    cache16 = torch.randn(npages, 2, ps, hkv, d, device=device, dtype=torch.float16, generator=g)
+    k8, scale_k = quant_per_head(cache16[:, 0], 2)
+    v8, scale_v = quant_per_head(cache16[:, 1], 2)
+    cache = torch.stack([k8, v8], dim=1).contiguous()
+    del cache16, k8, v8
+    q, scale_q = quant_per_head(torch.randn(b * qo, hq, d, device=device, dtype=torch.float16, generator=g), 1)
     qo_indptr = (torch.arange(b + 1, dtype=torch.int32) * qo).to(device)
     indptr = (torch.arange(b + 1, dtype=torch.int32) * (kv // ps)).to(device)
     indices = torch.randperm(npages, device=device, generator=g).to(torch.int32)
@@ -189,10 +200,11 @@ def secondary_workloads(device):
     w.plan(qo_indptr, indptr, indices, last, hq, hkv, d, ps, causal=True, q_data_type=torch.float8_e4m3fn,
            kv_data_type=torch.float8_e4m3fn, o_data_type=torch.bfloat16)
     o = torch.empty(b * qo, hq, d, device=device, dtype=torch.bfloat16)
-    ms = _time_ms(lambda: w.run(q, cache, out=o), iters=10, warm=3)
+    ms = _time_ms(lambda: w.run(q, cache, out=o, scale_q=scale_q, scale_k=scale_k, scale_v=scale_v), iters=10, warm=3)
     flops = b * (2 * kv - qo) * qo * hq * 2 * d
     out.append({"workload": "C3: BatchPrefillWithPagedKVCacheWrapper fp8_e4m3 causal qo_len=2048 kv_len=8192 bs=16 "
-                            "head_dim=128 GQA 32/8 page_size=16", "ms": ms, "value": flops / ms / 1e9,
+                            "head_dim=128 GQA 32/8 page_size=16, per-head quantised q/k/v with their scales",
+                "ms": ms, "value": flops / ms / 1e9,
                 "unit": "TFLOP/s", "dtype": "fp8_e4m3",
                 "roofline": {"bound": "mfma", "achieved": flops / ms / 1e9, "peak": 5000.0, "unit": "TFLOP/s",
                              "frac": flops / ms / 1e9 / 5000.0, "kernel": "fi::batch_prefill_fp8_kernel"},
@@ -258,13 +270,24 @@ def c5_cascade(device, world, rank, dist, iters=200, warm=30):
             q_local, lambda qa: pw_s.run(qa, cache_s, return_lse=True), lambda ql: dw.run(ql, cache_u, return_lse=True),
             flashinfer.merge_states, flashinfer.merge_state, exchange=ex)
 
+    # the one-collective form: q already on every rank (replicated upstream), no all-gather in the step
+    q_rep = torch.zeros(B * world, HQ, D, device=device, dtype=torch.bfloat16)
+    q_rep[rank * B:(rank + 1) * B] = q_local
+    if dist.get_world_size() > 1:
+        dist.all_reduce(q_rep)  # setup, outside the timed loops: every rank's rows (the others are zero here)
+
+    def sharded_q_replicated():
+        return fdist.sharded_shared_prefix_decode(
+            q_local, lambda qa: pw_s.run(qa, cache_s, return_lse=True), lambda ql: dw.run(ql, cache_u, return_lse=True),
+            flashinfer.merge_states, flashinfer.merge_state, exchange=ex, q_all=q_rep)
+
     def replicated():
         v_p, s_p = pw_r.run(q_local, cache_r, return_lse=True)
         v_u, s_u = dw.run(q_local, cache_u, return_lse=True)
         return flashinfer.merge_state(v_p, s_p, v_u, s_u)[0]
 
     res = {}
-    for name, fn in (("sharded", sharded), ("replicated", replicated)):
+    for name, fn in (("sharded", sharded), ("sharded_q_replicated", sharded_q_replicated), ("replicated", replicated)):
         for _ in range(warm):
             fn()
         torch.cuda.synchronize()
@@ -283,8 +306,11 @@ def c5_cascade(device, world, rank, dist, iters=200, warm=30):
         "workload": f"C5: cascade shared-prefix batch decode bs={B * world} over {world} GPU(s) (64/GPU), bf16 GQA 32/8 "
                     f"d128 page 16, prefix {PREFIX} + {UNIQUE} unique tokens",
         "rccl_ranks": dist.get_world_size(), "backend": dist.get_backend(),
-        "collectives_per_step": "1 all_gather_into_tensor (q) + 1 all_to_all_single (packed v|lse states)",
-        "us_per_step_sharded_prefix": res["sharded"] * 1e6, "us_per_step_replicated_prefix": res["replicated"] * 1e6,
+        "collectives_per_step": "sharded: 1 all_gather_into_tensor (q) + 1 all_to_all_single (packed v|lse states); "
+                                "sharded_q_replicated: the all_to_all_single alone (q replicated upstream)",
+        "us_per_step_sharded_prefix": res["sharded"] * 1e6,
+        "us_per_step_sharded_prefix_q_replicated": res["sharded_q_replicated"] * 1e6,  # ONE collective (all_to_all)
+        "us_per_step_replicated_prefix": res["replicated"] * 1e6,
         "requests_per_s_sharded": B * world / res["sharded"], "requests_per_s_replicated": B * world / res["replicated"],
         "state_bytes_sent_per_rank_per_step": ex.bytes_sent_per_step,
         "q_bytes_gathered_per_rank_per_step": (world - 1) * B * HQ * D * 2,
@@ -307,6 +333,7 @@ def main():
     ap.add_argument("--no-permute", action="store_true", help="arange page table instead of a random permutation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 side measurements (N=1 only)")
+    ap.add_argument("--no-c5", action="store_true", help="N=1: skip the cascade exchange step on a one-rank RCCL group")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -372,7 +399,22 @@ def main():
 
     nbytes, flops = algorithmic_bytes_flops(cfg)
     c5 = None
-    if distributed:  # the one exchange step of the path (RCCL all-to-all of shared-prefix states), every rank
+    if not distributed and not args.no_c5:
+        # N = 1 from the driver: the exchange step still runs through RCCL, on a one-rank group (the collectives
+        # degenerate to local copies inside the library, but it is the same code path the N > 1 runs take)
+        try:
+            import datetime
+
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device,
+                                    timeout=datetime.timedelta(minutes=5))
+            distributed = True
+        except Exception as exc:
+            c5 = {"error": "one-rank RCCL group: " + repr(exc)}
+    if distributed and c5 is None:  # the one exchange step of the path (RCCL all-to-all of shared-prefix states)
         try:
             c5 = c5_cascade(device, world, rank, dist)
         except Exception as exc:

@@ -17,8 +17,18 @@ static hipError_t launch_v2(const PrefillKernelParams& p, int head_dim, int grid
     if (uni) batch_prefill_fp8_kernel<OUT16, true, 8, BF8><<<dim3(grid), dim3(512), 0, stream>>>(p);
     else batch_prefill_fp8_kernel<OUT16, false, 8, BF8><<<dim3(grid), dim3(512), 0, stream>>>(p);
   } else {
-    if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-    else batch_prefill_fp8_kernel<OUT16, false, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    // FI_PREFILL_FP8_LAG=0: the second structure (P.V of a tile right behind its softmax) for A/B runs
+    static const bool lag = [] {
+      const char* e = getenv("FI_PREFILL_FP8_LAG");
+      return !(e && atoi(e) == 0);
+    }();
+    if (lag) {
+      if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8, 128, true><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+      else batch_prefill_fp8_kernel<OUT16, false, 4, BF8, 128, true><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    } else {
+      if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+      else batch_prefill_fp8_kernel<OUT16, false, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    }
   }
   return hipGetLastError();
 }

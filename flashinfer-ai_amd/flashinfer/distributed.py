@@ -179,6 +179,7 @@ def sharded_shared_prefix_decode(
     group: Optional[dist.ProcessGroup] = None,
     batch_sizes: Optional[Sequence[int]] = None,
     exchange: Optional[SharedPrefixExchange] = None,
+    q_all: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """One decode step with a sequence-sharded shared prefix.
 
@@ -192,6 +193,10 @@ def sharded_shared_prefix_decode(
         holds as many queries as this one.  A mismatch cannot be detected without a collective: with
         unequal slices and no batch_sizes the gather fails inside the backend.
     exchange: a `SharedPrefixExchange` built once for the loop (buffers are reused); built here otherwise.
+    q_all: every rank's queries in the padded rank-major layout [world * max(batch_sizes), H, D], when the
+        caller already holds them on every rank (a tensor-parallel model replicates the activations that
+        produce q, SURVEY.md 8e "or replicate q upstream"): the query all-gather is skipped and the step has
+        ONE collective, the all-to-all of the partial states.
     """
     world, _ = _world_rank(group)
     if world == 1 and exchange is None:
@@ -202,7 +207,11 @@ def sharded_shared_prefix_decode(
     if exchange is None:
         exchange = SharedPrefixExchange(q_local.shape[1], q_local.shape[2], q_local.dtype, q_local.device,
                                         q_local.shape[0], batch_sizes, group)
-    q_all = exchange.gather_queries(q_local)
+    if q_all is None:
+        q_all = exchange.gather_queries(q_local)
+    elif q_all.shape != (exchange.world * exchange.b_max, exchange.h, exchange.d):
+        raise ValueError(f"q_all must be {(exchange.world * exchange.b_max, exchange.h, exchange.d)}, "
+                         f"got {tuple(q_all.shape)}")
     v_p, s_p = prefix_attend(q_all)
     v_u, s_u = unique_attend(q_local)
     v_x, s_x = exchange.exchange(v_p, s_p)

@@ -499,3 +499,56 @@ def test_fp8_prefill_through_the_256_row_tile_form():
                         "no:cacheprovider"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout
+
+
+def _peaked_fp8_case(f8, d, kv_len, qo_len, tail_lo, tail_hi, peak, seed):
+    """q rows close to one +-1 vector u, keys = g_j u / sqrt(d): the logit of key j is ~g_j nats for every query.
+    One key (visible to every query under the causal mask) sits at `peak`, the others uniformly in
+    [tail_lo, tail_hi]; the values of the tail have mean +1, the peak key's value is -2, so lost tail mass moves
+    every output element the same way."""
+    g = torch.Generator().manual_seed(seed)
+    h = 2
+    u = (torch.randint(0, 2, (d,), generator=g) * 2 - 1).float()
+    q = u[None, None, :] + 0.05 * torch.randn(qo_len, h, d, generator=g)
+    gj = tail_lo + (tail_hi - tail_lo) * torch.rand(kv_len, h, generator=g)
+    jstar = int(torch.randint(0, kv_len - qo_len, (1,), generator=g))
+    gj[jstar] = peak
+    k = gj[:, :, None] * u[None, None, :] / d ** 0.5
+    v = torch.randn(kv_len, h, d, generator=g) * 0.5 + 1.0
+    v[jstar] = -2.0
+    return q.to(f8), k.to(f8), v.to(f8), jstar
+
+
+@pytest.mark.parametrize("f8", [torch.float8_e4m3fn, torch.float8_e5m2])
+@pytest.mark.parametrize("d", [64, 128])
+def test_fp8_prefill_peaked_rows(f8, d):
+    """Long, peaked rows: one key at +12 nats, 8191 keys at -2..0 nats.  The tail terms are
+    e^-12..e^-14 of the row maximum, i.e. at the bottom of the e4m3 range of P (the reference scales P by 448
+    against the running maximum, hopper/variants.cuh:72-90: its subnormal step is 4.4e-6 of the maximum; this
+    kernel forms P against a deferred reference exponent with 2^3 of headroom, so right after the exponent was set
+    its step is up to 8x coarser, prefill_fp8_kernel.h).  What the test pins: (1) the result stays inside the fp8 bar
+    against the oracle's restatement of the reference arithmetic, (2) against exact attention on the same fp8
+    inputs the error is bounded by the tail mass of the row (2 %), whichever way the tail was rounded, (3) the
+    lse, which comes from the unrounded probabilities, is exact to f32."""
+    import flashinfer
+
+    kv_len, qo_len = 8192, 64
+    q8, k8, v8, _ = _peaked_fp8_case(f8, d, kv_len, qo_len, -2.0, 0.0, 12.0, seed=11)
+    one = torch.ones(2)
+    o, lse = flashinfer.single_prefill_with_kv_cache(q8.to(DEV), k8.to(DEV), v8.to(DEV), one.to(DEV), one.to(DEV),
+                                                     one.to(DEV), causal=True, o_dtype=torch.float16,
+                                                     return_lse=True)
+    o = o.float().cpu()
+    o_ref8, lse_ref = R.fp8_attention_ref(q8, k8, v8, one, one, one, causal=True)
+    o_16, _ = R.attention_ref(q8.float(), k8.float(), v8.float(), causal=True)
+    err8 = (o - o_ref8.float()).abs().max().item()
+    err16 = (o - o_16.float()).abs().max().item()
+    ref_err16 = (o_ref8.float() - o_16.float()).abs().max().item()
+    print(f"peaked rows {f8} d={d}: |o - fp8 oracle| {err8:.4f}  |o - exact| {err16:.4f}  "
+          f"(fp8 oracle vs exact {ref_err16:.4f})")
+    bar = 5e-2 if f8 == torch.float8_e4m3fn else 1e-1
+    assert err8 < bar
+    # exact attention: o = (-2 + eps * ~1) / (1 + eps) with eps = tail mass / peak mass ~ 0.02; all of the tail lost
+    # costs 3 eps ~ 0.066 at most (the e5m2 grid of P is one octave coarser at the same exponent range)
+    assert err16 < 0.07
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-4, atol=1e-3)
