@@ -285,302 +285,19 @@ __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const G
   }
 }
 
-// ---- 256 x 128 tile kernel for large problems -------------------------------------------------------------
-// One 512-thread workgroup per CU owns a 256 (m) x 128 (n) tile: 8 waves of 64 x 64, two per SIMD.  Per
-// thread and k block only 6 operand loads (24 registers) are in flight instead of 8, which leaves room for a
-// SECOND register stage: global loads run two k blocks ahead of the MFMAs, so an L2 / HBM round trip has two
-// full k steps to complete.  The tile also needs 25 % fewer operand bytes per flop from L2 (170 flop/B; at
-// 128 flop/B the measured 17-19 TB/s of L2 caps the kernel near 2.2 PFLOP/s) and 25 % fewer LDS stores.
+// ---- 256 x 128 tile persistent kernel for large problems (LDS-DMA staging) --------------------------------------
+// One 512-thread workgroup per CU owns a 256 (m) x 128 (n) tile (or 128 x 256, TM): 8 waves of 64 x 64, two per SIMD;
+// the tile needs 25 % fewer operand bytes per flop from L2 than 128 x 128 (170 flop/B).  (r1's register-staged form
+// of this kernel was removed in r3: the DMA form below replaced it as the default in r1 and nothing selected it.)
 constexpr int kWsThreads = 512;
 constexpr int kWsBM = 256;
-#ifndef FI_GEMM_WIDE_AHEAD
-#define FI_GEMM_WIDE_AHEAD 2
-#endif
-constexpr int kAhead = FI_GEMM_WIDE_AHEAD;
-#ifndef FI_GEMM_KO
-#define FI_GEMM_KO 0  // experiments only, bit mask: 1 no output stores, 2 no fold, 4 no operand loads in the k loop, 8 no LDS stores, 16 LDS fragment reads only in even k steps
-#endif
-
-template <bool MA_E5M2, bool MB_E5M2>
-__global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_wide_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) uint8_t smem[2][(kWsBM + kBN) * kBK];  // [stage][A 32 KB | B 16 KB]
-  constexpr int kBOff = kWsBM * kBK;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave & 3, wn = wave >> 2;
-  const int lq = lane & 31, lh = lane >> 5;
-  const int K = p.k, N = p.n;
-  const int kblocks = K / kBK;
-  auto lds_off = [](int row, int ch) { return row * kBK + ((ch ^ ((row >> 1) & 7)) << 4); };
-  const int st_row = tid >> 3, st_ch = tid & 7;  // staging: passes of 64 rows x 8 chunks; A 4 passes, B 2
-  const int m_cnt = p.a_gran_m == 1 ? p.m_total : (p.m_total + p.a_gran_m - 1) / p.a_gran_m;
-  const int a_sc_stride = p.scale_k_major ? 1 : m_cnt;
-  const int n_sblocks = (N + 127) / 128;
-  const int b_sc_stride = p.scale_k_major ? 1 : n_sblocks;
-  // LDS read addresses: every fragment address is one per-lane base XOR a literal (the k half flips chunk
-  // bit 2, the second 16 bytes chunk bit 0) plus a literal; the bases pass through an empty asm in the loop
-  // so that the derived addresses are recomputed there instead of living in 16 registers
-  uint32_t a_rd_base = (uint32_t)lds_off(64 * wm + lq, 2 * lh);
-  uint32_t b_rd_base = (uint32_t)(kBOff + lds_off(64 * wn + lq, 2 * lh));
-
-  // ---- persistent workgroup: the XCD-contiguous tile range of this XCD, strided by its workgroups ----
-  const int total = p.num_m_tiles_bound * p.n_tiles;
-  int logical, logical_end;
-  const int logical_step = gridDim.x >> 3;
-  {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int qn = total >> 3, rn = total & 7;
-    const int start = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-    logical = start + slot;
-    logical_end = start + qn + (xcd < rn ? 1 : 0);
-  }
-
-  f32x16g acc[2][2];  // [n block][m block]
-  int out_m0 = 0, out_n0 = 0, out_m_end = 0;  // tile whose accumulators are waiting to be stored
-  bool have_out = false;
-  // Output: the accumulators are transposed (m on the lane), so a direct store writes 8-byte pieces.  Each
-  // wave instead turns its 64 x 64 block through its own 9 KB of LDS ([m][64 n] bf16/f16 rows, 144-byte row
-  // stride) and stores whole 128-byte rows, 16 bytes per lane.  Callers put a workgroup barrier between this
-  // and the next LDS stage store.
-  constexpr int kOutStride = 144;
-  const bool d_aligned16 = (((uintptr_t)p.d) & 15) == 0;
-  auto store_tile = [&]() {
-    uint8_t* const scratch = &smem[0][0] + wave * (64 * kOutStride);
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          uint32_t w[2];
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const uint32_t lo = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e], p.out_dtype);
-            const uint32_t hi = f32_to_16bit(acc[nb][mb][4 * r4 + 2 * e + 1], p.out_dtype);
-            w[e] = lo | (hi << 16);
-          }
-          *(u32x2*)(scratch + (32 * mb + lq) * kOutStride + (32 * nb + 8 * r4 + 4 * lh) * 2) = u32x2{w[0], w[1]};
-        }
-#pragma unroll
-    for (int i2 = 0; i2 < 8; ++i2) {
-      const int idx = lane + 64 * i2;
-      const int r = idx >> 3, c = idx & 7;
-      const u32x4 v = *(const u32x4*)(scratch + r * kOutStride + c * 16);
-      const int m = out_m0 + 64 * wm + r;
-      const int n = out_n0 + 64 * wn + 8 * c;
-      if (m >= out_m_end || n >= N) continue;  // n is a multiple of 8 and so is N
-      uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
-      if (d_aligned16) {
-        *(u32x4*)dst = v;
-      } else {
-        *(u32x2*)dst = u32x2{v[0], v[1]};
-        *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};
-      }
-    }
-  };
-
-  for (; logical < logical_end; logical += logical_step) {
-    constexpr int kBandM = 4;  // 1024 rows x all n per band, as in the 128 x 128 kernel
-    const int band_tiles = kBandM * p.n_tiles;
-    const int band = logical / band_tiles;
-    const int in_band = logical - band * band_tiles;
-    const int band_m = min(kBandM, p.num_m_tiles_bound - band * kBandM);
-    const int nt = in_band / band_m;
-    const int mt_global = band * kBandM + (in_band - nt * band_m);
-    int g = 0, m_begin = 0, m_end = p.m_total, mt = mt_global;
-    bool found = true;
-    if (p.m_indptr) {
-      found = find_group_tile<kWsBM>(p.m_indptr, p.num_groups, mt_global, lane, g, m_begin, m_end, mt);
-    } else if (mt_global * kWsBM >= p.m_total) {
-      found = false;
-    }
-    if (!found) continue;  // the grid bound counts one partial tile per group; uniform per workgroup
-    const int m0 = m_begin + mt * kWsBM;
-    const int n0 = nt * kBN;
-    const uint8_t* Bg = p.b + (int64_t)g * N * K;
-
-    struct StageRegs {
-      u32x4 a[4], b[2];
-    };
-    StageRegs rs0, rs1;  // k block b travels in rs(b & 1)
-    const uint8_t* const a_tile = p.a + (int64_t)m0 * K;
-    const uint8_t* const b_tile = Bg + (int64_t)n0 * K;
-    uint32_t a_off[4], b_off[2];
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps)
-      a_off[ps] = (uint32_t)(min(m0 + ps * 64 + st_row, m_end - 1) - m0) * (uint32_t)K + st_ch * 16;
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps)
-      b_off[ps] = (uint32_t)(min(n0 + ps * 64 + st_row, N - 1) - n0) * (uint32_t)K + st_ch * 16;
-    auto issue = [&](int kb, StageRegs& r) {
-      const uint32_t koff = (uint32_t)(min(kb, kblocks - 1) * kBK);
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) r.a[ps] = *(const u32x4*)(a_tile + (a_off[ps] + koff));
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) r.b[ps] = *(const u32x4*)(b_tile + (b_off[ps] + koff));
-    };
-    auto commit = [&](int buf, const StageRegs& r) {
-#pragma unroll
-      for (int ps = 0; ps < 4; ++ps) *(u32x4*)(&smem[buf][lds_off(ps * 64 + st_row, st_ch)]) = r.a[ps];
-#pragma unroll
-      for (int ps = 0; ps < 2; ++ps) *(u32x4*)(&smem[buf][kBOff + lds_off(ps * 64 + st_row, st_ch)]) = r.b[ps];
-    };
-    // scales: one pointer per lane and m block + a uniform k stride; the B scale pointer is wave uniform
-    const float* const b_sc = p.scale_k_major ? p.b_scale + ((int64_t)g * n_sblocks + n0 / 128) * kblocks
-                                              : p.b_scale + (int64_t)g * kblocks * n_sblocks + n0 / 128;
-    const float* a_sc[2];
-#pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
-      const int m = min(m0 + 64 * wm + 32 * mb + lq, m_end - 1);
-      const int mi = p.a_gran_m == 1 ? m : m / p.a_gran_m;
-      a_sc[mb] = p.scale_k_major ? p.a_scale + (int64_t)mi * kblocks : p.a_scale + mi;
-    }
-    float sa_nxt[2], sb_nxt;
-    auto load_scales = [&](int kb) {
-      const int kc = min(kb, kblocks - 1);
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb) sa_nxt[mb] = a_sc[mb][(int64_t)kc * a_sc_stride];
-      sb_nxt = b_sc[(int64_t)kc * b_sc_stride];
-    };
-
-    // the first loads of this tile go out before the previous tile's accumulators are converted and stored:
-    // with one workgroup per CU nothing else would cover either the stores or the first round trip
-    load_scales(0);
-    issue(0, rs0);
-    if constexpr (kAhead == 2) issue(1, rs1);
-    if (have_out && !(FI_GEMM_KO & 1)) {
-      store_tile();
-      __syncthreads();  // the transposition scratch overlaps LDS stage 0
-    }
-    out_m0 = m0;
-    out_n0 = n0;
-    out_m_end = m_end;
-    have_out = true;
-#pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2)
-#pragma unroll
-      for (int j2 = 0; j2 < 2; ++j2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i2][j2][r] = 0.f;
-    commit(0, rs0);
-    __syncthreads();
-    f32x16g p_carry;  // block (1, 1) of the previous k step, folded at the start of the next one
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p_carry[r] = 0.f;
-    float s_carry = 0.f;
-
-    auto k_step = [&](auto par_c, const int kb, StageRegs& r_free, const StageRegs& r_next) {
-      constexpr int buf = decltype(par_c)::value;  // == kb & 1
-      // the scales of block kb were loaded one step ago and the next ones are requested BEFORE this step's
-      // operand loads: vmcnt retires in order, so a scale load issued after them would make the first fold
-      // wait for the whole prefetch
-      const float sa[2] = {sa_nxt[0], sa_nxt[1]};
-      const float sb = sb_nxt;
-      load_scales(kb + 1);
-      if (!(FI_GEMM_KO & 4)) issue(kb + kAhead, r_free);  // block kb's registers went to LDS one step ago
-      asm volatile("" : "+v"(a_rd_base), "+v"(b_rd_base));
-      const uint8_t* const stage = &smem[buf][0];
-      // One 32 x 32 block at a time, in four scheduling regions.  Region i holds: the LDS reads the NEXT
-      // block needs, block i's two MFMAs, the fold of block i - 1 (vector pipe beside matrix pipe) and a
-      // third of the LDS stores of k block kb + 1 -- so the stores and reads ride in the shadow of the
-      // MFMAs instead of forming their own phase before the barrier (every wave of the workgroup is in the
-      // same phase: a read-only or store-only phase leaves the matrix pipe idle).  Nothing crosses a region
-      // border: left alone the scheduler hoists every LDS read and all four partial products to the top and
-      // spills ~30 registers.
-      auto frag = [&](uint32_t base, int kk, int blk) {
-        if (FI_GEMM_KO & 16) return i32x8g{(int)base, kk, blk, (int)base, kk, blk, (int)base, 0x38383838};
-        const u32x4 lo = *(const u32x4*)(stage + ((base ^ (kk << 6)) + blk * 32 * kBK));
-        const u32x4 hi = *(const u32x4*)(stage + ((base ^ (kk << 6) ^ 16) + blk * 32 * kBK));
-        return i32x8g{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
-      };
-      auto mfma0 = [&](const i32x8g& b, const i32x8g& a) {
-        f32x16g z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, z, MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0,
-                                                               0x7F7F7F7F, 0, 0x7F7F7F7F);
-      };
-      auto mfma1 = [&](const i32x8g& b, const i32x8g& a, const f32x16g& c) {
-        return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0,
-                                                               0x7F7F7F7F, 0, 0x7F7F7F7F);
-      };
-      auto fold = [&](int nb, int mb, const f32x16g& part, float s) {
-#pragma unroll
-        for (int r = 0; r < ((FI_GEMM_KO & 2) ? 1 : 16); ++r) acc[nb][mb][r] += s * part[r];
-        asm volatile("" : "+v"(acc[nb][mb]));  // IR-level sinking ignores sched_barrier: pin the fold here
-      };
-      const StageRegs& rc = kAhead == 2 ? r_next : r_free;  // k block kb + 1
-      uint8_t* const wr = &smem[buf ^ 1][0];
-      auto commit_a = [&](int ps) { *(u32x4*)(wr + lds_off(ps * 64 + st_row, st_ch)) = rc.a[ps]; };
-      auto commit_b = [&](int ps) { *(u32x4*)(wr + kBOff + lds_off(ps * 64 + st_row, st_ch)) = rc.b[ps]; };
-      const float s0 = sa[0] * sb, s1 = sa[1] * sb;
-      i32x8g fa0[2], fa1[2], fb0[2], fb1[2];
-      // The two MFMAs of a block are dependent (same accumulator): the second cannot issue for the 64 cycles
-      // the first one runs, and neither can anything behind it in this wave.  So the previous block's fold
-      // (and the LDS stores) sit BETWEEN the two, in the shadow of the first.
-      // region 0: fragment reads, the fold carried over from the previous k step hides their latency
-      fa0[0] = frag(a_rd_base, 0, 0);
-      fb0[0] = frag(b_rd_base, 0, 0);
-      fa0[1] = frag(a_rd_base, 1, 0);
-      fb0[1] = frag(b_rd_base, 1, 0);
-      fa1[0] = frag(a_rd_base, 0, 1);
-      fa1[1] = frag(a_rd_base, 1, 1);
-      fold(1, 1, p_carry, s_carry);
-      __builtin_amdgcn_sched_barrier(0);
-      f32x16g p00 = mfma0(fb0[0], fa0[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      fb1[0] = frag(b_rd_base, 0, 1);
-      fb1[1] = frag(b_rd_base, 1, 1);
-      if (!(FI_GEMM_KO & 8)) { commit_a(0); commit_a(1); }
-      __builtin_amdgcn_sched_barrier(0);
-      p00 = mfma1(fb0[1], fa0[1], p00);
-      // region 1
-      f32x16g p01 = mfma0(fb0[0], fa1[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(0, 0, p00, s0);
-      if (!(FI_GEMM_KO & 8)) { commit_a(2); commit_a(3); }
-      __builtin_amdgcn_sched_barrier(0);
-      p01 = mfma1(fb0[1], fa1[1], p01);
-      // region 2
-      f32x16g p10 = mfma0(fb1[0], fa0[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(0, 1, p01, s1);
-      if (!(FI_GEMM_KO & 8)) { commit_b(0); commit_b(1); }
-      __builtin_amdgcn_sched_barrier(0);
-      p10 = mfma1(fb1[1], fa0[1], p10);
-      // region 3
-      f32x16g p11 = mfma0(fb1[0], fa1[0]);
-      __builtin_amdgcn_sched_barrier(0);
-      fold(1, 0, p10, s0);
-      __builtin_amdgcn_sched_barrier(0);
-      p11 = mfma1(fb1[1], fa1[1], p11);
-      p_carry = p11;
-      s_carry = s1;
-      __syncthreads();
-      __builtin_amdgcn_sched_barrier(0);  // no mixing of two k steps either
-    };
-    {
-      int kb = 0;
-      for (; kb + 1 < kblocks; kb += 2) {
-        k_step(std::integral_constant<int, 0>{}, kb, rs0, rs1);
-        k_step(std::integral_constant<int, 1>{}, kb + 1, rs1, rs0);
-      }
-      if (kb < kblocks) k_step(std::integral_constant<int, 0>{}, kb, rs0, rs1);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[1][1][r] += s_carry * p_carry[r];
-  }
-  if (have_out && (!(FI_GEMM_KO & 1) || p.k == 12345)) store_tile();
-}
 
 // ---- the same 256 x 128 persistent kernel with LDS-DMA staging (default for large problems) --------------
 // Operands go global -> LDS directly (`global_load_lds_dwordx4`, 1 KiB per wave instruction), two k blocks
 // ahead through a ring of three 52 KB LDS stages (156 of the 160 KB): no staging registers, no
 // VGPR -> LDS store transfer.  Synchronisation is by hand: every wave waits `vmcnt(8)` (its own pieces of the
 // NEXT block landed, the 8 DMA instructions of the block after it still in flight) and then a raw `s_barrier`
-// -- `__syncthreads()` would drain vmcnt.  FI_GEMM_DMA=0 selects the register-staged kernel above.
+// -- `__syncthreads()` would drain vmcnt.
 template <bool MA_E5M2, bool MB_E5M2, int TM>
 __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const GemmParams p) {
   // TM x TN output tile, TM + TN = 384 rows of operands per k block: 256 x 128, or 128 x 256 for groups of few
@@ -900,10 +617,7 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
   const int ws_tiles = p.num_m_tiles_bound_ws * p.n_tiles;
   const int ws_grid = (fi_num_compute_units() / 8) * 8;  // persistent: one workgroup per CU, XCD-aligned
   const bool use_ws = use_mx && ws_min_tiles >= 0 && ws_tiles >= ws_min_tiles && ws_grid >= 8;
-  static const bool use_dma = [] {
-    const char* e = getenv("FI_GEMM_DMA");  // 0: the register-staged 256 x 128 kernel
-    return e ? atoi(e) != 0 : true;
-  }();
+  constexpr bool use_dma = true;
   // 128 x 256 tiles for grouped problems whose groups have few rows (a <= 128-row group fills half of a
   // 256-row tile); FI_GEMM_DMA_TM = 128 / 256 forces the shape
   static const int forced_tm = [] {
@@ -943,17 +657,6 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
       case 1: group_gemm_fp8_dma_kernel<false, true, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
       case 2: group_gemm_fp8_dma_kernel<true, false, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
       default: group_gemm_fp8_dma_kernel<true, true, 256><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-    }
-    return hipGetLastError();
-  }
-  if (use_ws) {
-    GemmParams q = p;
-    q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
-    switch (sel) {
-      case 0: group_gemm_fp8_wide_kernel<false, false><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-      case 1: group_gemm_fp8_wide_kernel<false, true><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-      case 2: group_gemm_fp8_wide_kernel<true, false><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
-      default: group_gemm_fp8_wide_kernel<true, true><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(q); break;
     }
     return hipGetLastError();
   }
@@ -1020,6 +723,7 @@ extern "C" FI_API int fi_gemm_fp8_nt_groupwise(const void* a, const void* b, con
     return 1;
   p.num_groups = 1;
   p.m_indptr = nullptr;
+  p.pow2_flag = nullptr;
   p.num_m_tiles_bound = ceil_div(m, kBM);
   p.num_m_tiles_bound_ws = ceil_div(m, kWsBM);
   FI_HIP_CALL(launch_gemm(p, (hipStream_t)stream));
@@ -1042,6 +746,7 @@ extern "C" FI_API int fi_group_gemm_fp8_nt_groupwise(const void* a, const void* 
   FI_REQUIRE(m_indptr, "group_gemm_fp8_nt_groupwise: null m_indptr");
   p.num_groups = num_groups;
   p.m_indptr = m_indptr;
+  p.pow2_flag = nullptr;
   // every group adds at most one partial tile on top of cum_m / 128
   p.num_m_tiles_bound = cum_m / kBM + num_groups;
   p.num_m_tiles_bound_ws = cum_m / kWsBM + num_groups;

@@ -18,6 +18,8 @@
 //   * output through LDS (stage 1, free at a tile border) as whole 128-byte row pieces.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
 #include <type_traits>
 
 #include "gemm_common.h"
@@ -39,8 +41,30 @@ constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64
 #define FI_GEMM_BIG_KO 0  // experiments only, bit mask: 1 no output stores, 2 no fold, 4 no DMA in the k loop
 #endif
 
-template <bool MA_E5M2, bool MB_E5M2>
+// 1 in *flag when some scale is not a positive normal power of two (flag zeroed by the launcher).  HBM-bound, a few
+// microseconds: C4's a_scale is 4 MB.
+__global__ void __launch_bounds__(256) scales_pow2_check_kernel(const uint32_t* a_scale, int64_t na, const uint32_t* b_scale,
+                                                                  int64_t nb, uint32_t* flag) {
+  bool bad = false;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
+    const uint32_t w = i < na ? a_scale[i] : b_scale[i - na];
+    const uint32_t e = w >> 23;  // sign | exponent
+    bad |= (w & 0x007fffffu) != 0 || e == 0 || e >= 255;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// HWS: the scales are powers of two (checked on the device, p.pow2_flag): their exponents go to the MFMA as E8M0
+// block scales -- v_mfma_scale computes sum (a 2^sa)(b 2^sb) -- and every k block accumulates straight into the
+// tile's accumulators: no partial products, no fold (128 FMAs per 16 MFMAs and wave in the general path, 16 % of
+// the C4 launch).  Both instantiations are launched; the one the flag does not select returns at once.
+template <bool MA_E5M2, bool MB_E5M2, bool HWS>
 __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(const GemmParams p) {
+  {
+    const bool pow2 = p.pow2_flag != nullptr && *p.pow2_flag == 0;
+    if (pow2 != HWS) return;
+  }
   // ONE array: the compiler tells a DMA target from an LDS read by constant offsets inside one object
   __shared__ __attribute__((aligned(1024))) uint8_t smem[2 * kBigStage + 768];  // 2 stages, then the group table
   constexpr int kGroupTab = 2 * kBigStage;
@@ -296,6 +320,38 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
       const float* const sc = (const float*)(&smem[buf * kBigStage + kBigScOff + wave * 512]);
       const float sa[2] = {sc[lq], sc[32 + lq]};
       const float sb = sc[64 + lane];
+      if constexpr (HWS) {
+        // E8M0 = the f32 exponent field of a power of two.  MFMA A operand = B matrix rows (one scale per wave: sb),
+        // MFMA B operand = A matrix rows, the lane's row (sa)
+        const int e_b = (int)(__builtin_bit_cast(uint32_t, sb) >> 23);
+        const int e_a0 = (int)(__builtin_bit_cast(uint32_t, sa[0]) >> 23), e_a1 = (int)(__builtin_bit_cast(uint32_t, sa[1]) >> 23);
+        auto mfma_s = [&](const i32x8g& b, const i32x8g& a, const f32x16g& c, int ea) {
+          return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0, e_b, 0, ea);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int cur = nb & 1;
+          acc[nb][0] = mfma_s(fb[cur][0], fa[0][0], acc[nb][0], e_a0);
+          if (nb < 3) {
+            fb[cur ^ 1][0] = frag(b_rd_base, 0, nb + 1);
+            fb[cur ^ 1][1] = frag(b_rd_base, 1, nb + 1);
+          }
+          if (FI_GEMM_BIG_SPREAD && more) {
+            if (nb == 0) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+            if (nb == 1) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+            if (nb == 2) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+            if (nb == 3) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
+          }
+          acc[nb][1] = mfma_s(fb[cur][0], fa[1][0], acc[nb][1], e_a1);
+          acc[nb][0] = mfma_s(fb[cur][1], fa[0][1], acc[nb][0], e_a0);
+          acc[nb][1] = mfma_s(fb[cur][1], fa[1][1], acc[nb][1], e_a1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+      }
       fold(3, 1, p_carry, s_carry);
       __builtin_amdgcn_sched_barrier(0);
       const float s0 = sa[0] * sb, s1 = sa[1] * sb;
@@ -342,21 +398,69 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
       }
       if (kb < kblocks) k_step(std::integral_constant<int, 0>{}, kb);
     }
+    if constexpr (!HWS) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[3][1][r] += s_carry * p_carry[r];
+      for (int r = 0; r < 16; ++r) acc[3][1][r] += s_carry * p_carry[r];
+    }
   }
   if (have_out && (!(FI_GEMM_BIG_KO & 1) || p.k == 12345)) store_tile();
 }
 
-hipError_t launch_gemm_big(const GemmParams& p, int grid, hipStream_t stream) {
-  // MFMA A operand = GEMM matrix B, MFMA B operand = GEMM matrix A
-  const int sel = (p.b_is_e5m2 ? 2 : 0) | (p.a_is_e5m2 ? 1 : 0);
-  switch (sel) {
-    case 0: group_gemm_fp8_big_kernel<false, false><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
-    case 1: group_gemm_fp8_big_kernel<false, true><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
-    case 2: group_gemm_fp8_big_kernel<true, false><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
-    default: group_gemm_fp8_big_kernel<true, true><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
+// flag words for the power-of-two check: a ring of slots per device (a call's three kernels read / write ITS slot;
+// calls in flight on other streams use other slots), allocated at the first call outside a stream capture
+static uint32_t* pow2_flag_slot(hipStream_t stream) {
+  constexpr int kSlots = 1024;
+  static uint32_t* ring[64] = {nullptr};
+  static std::atomic<unsigned> next{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (ring[dev] == nullptr) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (ring[dev] == nullptr) {
+      uint32_t* ptr = nullptr;
+      if (hipMalloc(&ptr, kSlots * sizeof(uint32_t)) != hipSuccess) return nullptr;
+      ring[dev] = ptr;
+    }
   }
+  return ring[dev] + (next.fetch_add(1) % kSlots);
+}
+
+template <bool HWS>
+static void launch_big_variant(const GemmParams& p, int sel, int grid, hipStream_t stream) {
+  switch (sel) {
+    case 0: group_gemm_fp8_big_kernel<false, false, HWS><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
+    case 1: group_gemm_fp8_big_kernel<false, true, HWS><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
+    case 2: group_gemm_fp8_big_kernel<true, false, HWS><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
+    default: group_gemm_fp8_big_kernel<true, true, HWS><<<dim3(grid), dim3(kBigThreads), 0, stream>>>(p); break;
+  }
+}
+
+hipError_t launch_gemm_big(const GemmParams& p_in, int grid, hipStream_t stream) {
+  // MFMA A operand = GEMM matrix B, MFMA B operand = GEMM matrix A
+  GemmParams p = p_in;
+  const int sel = (p.b_is_e5m2 ? 2 : 0) | (p.a_is_e5m2 ? 1 : 0);
+  // FI_GEMM_HW_SCALES=0: never take the hardware-scale path (A/B runs)
+  static const bool hw_scales = [] {
+    const char* e = getenv("FI_GEMM_HW_SCALES");
+    return !(e && atoi(e) == 0);
+  }();
+  uint32_t* flag = hw_scales ? pow2_flag_slot(stream) : nullptr;
+  p.pow2_flag = flag;
+  if (flag != nullptr) {
+    const int kblocks = p.k / kBK;
+    const int64_t m_cnt = p.a_gran_m == 1 ? p.m_total : (p.m_total + p.a_gran_m - 1) / p.a_gran_m;
+    const int64_t na = m_cnt * kblocks;
+    const int64_t nb = (int64_t)(p.m_indptr ? p.num_groups : 1) * kblocks * ((p.n + 127) / 128);
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    scales_pow2_check_kernel<<<dim3(256), dim3(256), 0, stream>>>((const uint32_t*)p.a_scale, na, (const uint32_t*)p.b_scale,
+                                                                  nb, flag);
+    launch_big_variant<true>(p, sel, grid, stream);
+  }
+  launch_big_variant<false>(p, sel, grid, stream);
   return hipGetLastError();
 }
 

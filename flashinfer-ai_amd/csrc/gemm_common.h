@@ -23,6 +23,10 @@ struct GemmParams {
   int32_t num_m_tiles_bound_ws;  // the same for the 256-row tiles of the producer/consumer kernel
   int32_t n_tiles;
   int32_t a_is_e5m2, b_is_e5m2;
+  // 256 x 256 kernel only: device word written by scales_pow2_check_kernel before the launch -- 0: every a / b scale
+  // is an exact power of two (what the reference's quantiser produces, flashinfer/testing/utils.py:96-98), so the
+  // scales can ride the MFMA's hardware block scales; non-zero (or a null pointer): the general fold path
+  const uint32_t* pow2_flag;
 };
 
 using f32x16g = __attribute__((ext_vector_type(16))) float;

@@ -1,5 +1,4 @@
 // fp8-native prefill (prefill_fp8_kernel.h): launchers for the two output types.
-// FI_PREFILL_FP8_V1=1 selects the first structure (prefill_fp8_v1_kernel.h) for A/B runs.
 #include <stdlib.h>
 
 #include "prefill_fp8_kernel.h"
@@ -17,18 +16,8 @@ static hipError_t launch_v2(const PrefillKernelParams& p, int head_dim, int grid
     if (uni) batch_prefill_fp8_kernel<OUT16, true, 8, BF8><<<dim3(grid), dim3(512), 0, stream>>>(p);
     else batch_prefill_fp8_kernel<OUT16, false, 8, BF8><<<dim3(grid), dim3(512), 0, stream>>>(p);
   } else {
-    // FI_PREFILL_FP8_LAG=0: the second structure (P.V of a tile right behind its softmax) for A/B runs
-    static const bool lag = [] {
-      const char* e = getenv("FI_PREFILL_FP8_LAG");
-      return !(e && atoi(e) == 0);
-    }();
-    if (lag) {
-      if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8, 128, true><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-      else batch_prefill_fp8_kernel<OUT16, false, 4, BF8, 128, true><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-    } else {
-      if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-      else batch_prefill_fp8_kernel<OUT16, false, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-    }
+    if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    else batch_prefill_fp8_kernel<OUT16, false, 4, BF8><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
   }
   return hipGetLastError();
 }
@@ -36,17 +25,6 @@ static hipError_t launch_v2(const PrefillKernelParams& p, int head_dim, int grid
 hipError_t prefill_fp8_launch(const PrefillKernelParams& p, int out_dtype, int e5m2, int head_dim, hipStream_t stream) {
   const int grid = p.num_work * p.num_kv_heads;
   if (grid == 0) return hipSuccess;
-  static const bool v1 = [] {
-    const char* e = getenv("FI_PREFILL_FP8_V1");
-    return e && atoi(e) != 0;
-  }();
-  if (v1 && p.tile_q == kTileQ && !e5m2 && head_dim == 128) {
-    if (out_dtype == FI_DTYPE_BF16)
-      batch_prefill_fp8_v1_kernel<FI_DTYPE_BF16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-    else
-      batch_prefill_fp8_v1_kernel<FI_DTYPE_F16><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
-    return hipGetLastError();
-  }
   if (e5m2)
     return out_dtype == FI_DTYPE_BF16 ? launch_v2<FI_DTYPE_BF16, true>(p, head_dim, grid, stream)
                                       : launch_v2<FI_DTYPE_F16, true>(p, head_dim, grid, stream);

@@ -11,8 +11,8 @@
 // instructions from two waves at twice the rate of one); 64-key tiles; S^T = K Q^T with the query row on the
 // lane; O^T += V^T P^T with the S^T accumulator registers (as e4m3) as the B operand.
 //
-// What changed against the first structure (prefill_fp8_v1_kernel.h, 29 % of the MFMA peak, 25 vector
-// instructions per MFMA, matrix pipe idle two thirds of the time):
+// What changed against the first structure (r1: register-staged K / V, one softmax behind its own QK^T; 29 % of the
+// MFMA peak, 25 vector instructions per MFMA, matrix pipe idle two thirds of the time; removed in r3):
 //   * K / V tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction) three
 //     tiles ahead through a ring of four 16 KB stages: no staging registers, no ds_write, no vector load in
 //     the loop at all (hand-counted vmcnt + raw s_barrier; every LDS object lives in ONE array).  Both images
@@ -32,7 +32,7 @@
 #pragma once
 #include <type_traits>
 
-#include "prefill_fp8_v1_kernel.h"
+#include "prefill_kernel.h"
 
 #ifndef FI_PF8_KO
 #define FI_PF8_KO 0  // timing experiments only (results are wrong), bit mask: 1 no exp2, 2 no DMA in the steps,
@@ -45,6 +45,9 @@
 #endif
 
 namespace fi {
+
+using i32x8 = __attribute__((ext_vector_type(8))) int;
+using i32x2 = __attribute__((ext_vector_type(2))) int;
 
 // MFMA as an asm statement (v_mfma_scale_f32_32x32x64_f8f6f4, e4m3 x e4m3, unit block scales).  The compiler moves
 // builtin MFMAs freely -- across the step barrier and into back-to-back bursts -- while the pipeline below wants each
@@ -97,23 +100,6 @@ __device__ __forceinline__ i32x2 lds_tr8(int addr) {
   return w;
 }
 
-// 16-byte LDS read from an asm statement (hand-counted lgkmcnt, as lds_tr8)
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_b128(int addr) {
-  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
-  u32x4 w;
-  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(addr), "i"(OFF));
-  return w;
-}
-// two 8-byte LDS reads 256 bytes apart (rows r and r + 32 of a [64] uint64 table) from an asm statement
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_2xb64_rows32(int addr) {
-  static_assert(OFF >= 0 && OFF % 8 == 0 && OFF / 8 + 32 < 256, "ds_read2_b64 offset fields (units of 8 bytes)");
-  u32x4 w;
-  asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(w) : "v"(addr), "i"(OFF / 8), "i"(OFF / 8 + 32));
-  return w;
-}
-
 typedef __attribute__((address_space(3))) void f8_lds_void;
 typedef const __attribute__((address_space(1))) void f8_gbl_void;
 
@@ -128,10 +114,8 @@ typedef const __attribute__((address_space(1))) void f8_gbl_void;
 // D: head_dim 128, or 64 (NW = 4 only): rows of 64 bytes in the same ring (a stage keeps its 8 KB stride), one k step
 // per QK^T block and two P.V blocks -- two MFMAs each per 64-key step against the same softmax work, so that form is
 // vector-bound by construction and its step is written plainly (builtin MFMAs, no hand interleave).
-// LAG (head_dim 128): the third structure of the tile loop -- P.V runs one tile behind the softmax, see lag_step
-template <int OUT16, bool UNI, int NW, bool BF8, int D = 128, bool LAG = false>
+template <int OUT16, bool UNI, int NW, bool BF8, int D = 128>
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
-  static_assert(!LAG || (D == 128 && NW == 4), "the lagged pipeline is written for head_dim 128, four waves");
   static_assert(D == 128 || (D == 64 && NW == 4), "head_dim 128, or 64 with four waves");
   constexpr int ROWB = D;             // bytes per K / V row in LDS
   constexpr int SLOTS = ROWB / 16;    // 16-byte slots per row
@@ -273,8 +257,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     for (int e = 0; e < 2; ++e)
       k_rd[kk][e] = D == 128 ? lq * 128 + (((4 * kk + 2 * lh + e) ^ ((lq >> 1) & 7)) << 4)
                              : lq * 64 + (((2 * lh + e) ^ ((lq >> 2) & 3)) << 4);
-  // V^T fragment: see prefill_fp8_v1_kernel.h (transposed 8-bit read; lane i of a 16-lane group addresses row
-  // b = i >> 1, bytes 8 (i & 1) .. +8 of chunk 2 db + g)
+  // V^T fragment.  P is the B operand in accumulator order (lane (q, h) holds the 32 probabilities kv = 32 kb + 8 g
+  // + 4 h + e, kb < 2, g < 4, e < 4), so V must be the A operand with that k order along each head_dim row.  The V
+  // tile stays ROW-MAJOR in LDS and is transposed on the way out by ds_read_b64_tr_b8: in a 16-lane group, lanes 2b
+  // and 2b + 1 address the 16 bytes of "row b" (any row) and lane j receives byte j of rows 0..7 -- each lane
+  // gathers, per read, the 8 kv rows of its k order for its own head_dim column: lane i of a group addresses row
+  // b = i >> 1, bytes 8 (i & 1) .. +8 of chunk 2 db + g
   int v_rd[4];  // [db]; head_dim 64 uses the first two
   {
     const int i16 = lane & 15, g = (lane >> 4) & 1, b = i16 >> 1;
@@ -285,7 +273,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     for (int db = 0; db < 4; ++db) v_rd[db] = base ^ ((db & (DBLK - 1)) << 5);  // ring / stage / row-block offsets: immediates
   }
   uint64_t* const tab = (uint64_t*)(smem + kF8TabOff);
-  const int tab_rd = kF8TabOff + st_row * 8;  // LDS address of this thread's row in table slot 0 (LAG: asm reads)
   int32_t* const ids = (int32_t*)(smem + kF8IdsOff);
 
   // ---- running state ----
@@ -351,37 +338,14 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     __syncthreads();
     if (wave < 4) make_tab(wave, wave);  // tables of tiles 0..3 (clamped)
     __syncthreads();
+    dma_tile(0, 0);
+    dma_tile(1, 1);
+    dma_tile(2, 2);
+    // tiles 0 and 1 have landed (tile 2: this wave's 4 (NW = 8: 2) pieces in flight); wait + barrier as one
+    // statement (see the step)
     constexpr bool kFourPieces = NW == 4 && D == 128;  // LDS-DMA pieces per wave and tile: 4, else 2
-    // K or V rows of one tile alone (the lagged pipeline keeps K three tiles and V two tiles ahead)
-    auto dma_issue_one = [&](const char* thr, int dst_off, uint64_t off0, uint64_t off1) {
-      char* const dst = smem + dst_off + wave * 1024;
-      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(thr + off0), (f8_lds_void*)(dst), 16, 0, 0);
-      if constexpr (kFourPieces)
-        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(thr + off1), (f8_lds_void*)(dst + 4096), 16, 0, 0);
-    };
-    if constexpr (LAG) {
-      // issue order of the steady state (step t issues K of tile t+3, then V of tile t+2): K0 K1 V0 K2 V1
-      uint64_t a0, a1, b0, b1, c0, c1;
-      dma_offsets(0, a0, a1);
-      dma_offsets(1, b0, b1);
-      dma_offsets(2, c0, c1);
-      dma_issue_one(k_thr, 0 * kF8KTile, a0, a1);
-      dma_issue_one(k_thr, 1 * kF8KTile, b0, b1);
-      dma_issue_one(v_thr, kF8VOff + 0 * kF8KTile, a0, a1);
-      dma_issue_one(k_thr, 2 * kF8KTile, c0, c1);
-      dma_issue_one(v_thr, kF8VOff + 1 * kF8KTile, b0, b1);
-      // K of tiles 0 and 1 landed (V0, K2, V1 of this wave may be in flight)
-      if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory");
-    } else {
-      dma_tile(0, 0);
-      dma_tile(1, 1);
-      dma_tile(2, 2);
-      // tiles 0 and 1 have landed (tile 2: this wave's 4 (NW = 8: 2) pieces in flight); wait + barrier as one
-      // statement (see the step)
-      if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-    }
+    if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
 
     // ---- building blocks ----
     const i32x8 q0 = qf[0], q1 = qf[1];
@@ -643,174 +607,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
         else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
     };
-    // ---- third structure (LAG): P.V runs one tile behind the softmax ----
-    // Step t turns the scores of tile t (sc) into probabilities while BOTH the QK^T MFMAs of tile t+1 (-> sn) and the
-    // P.V MFMAs of tile t-1 (pp: its e4m3 probabilities, formed in step t-1) are issued: eight MFMAs evenly spaced
-    // with half an exp2 chunk (4 fma, 4 exp2, 4 add, 2 cvt) in every gap.  In the second structure the four P.V
-    // MFMAs of a step sat back to back behind the whole softmax of their own tile -- 256 pipe cycles during which
-    // the wave issued nothing, and a softmax phase during which the pipe idled; whether the partner wave of the SIMD
-    // filled either was left to chance.  Here a wave's own stream keeps both busy.
-    //   ring: K of tile t+1 is read (stage (t+1)&3), V of tile t-1 (stage (t-1)&3); the step issues the DMA of K for
-    //   tile t+3 and of V for tile t+2 (the stage V of tile t-2 left at the last barrier); at the step's end K of
-    //   tile t+2 must have landed: the wave's V(t+1), K(t+3), V(t+2) pieces may stay in flight = vmcnt(6).
-    //   Every LDS read of the step is an asm statement; they return in order, so each wait is "all but the reads
-    //   issued after the one needed" (counts in the table below, FIRST: no V reads).
-    //   A rescale (rare path) happens at the END of a step: all four P.V MFMAs of tile t-1 (old exponent) have been
-    //   issued and are awaited before O is touched; the probabilities of tile t are then formed again.
-    auto lag_step = [&](auto stage_c, auto mask_c, auto first_c, f32x16 (&sc)[2], f32x16 (&sn)[2], const i32x8& pp,
-                        i32x8& pn, const int t) {
-      constexpr int ST = decltype(stage_c)::value;
-      constexpr bool MASK = decltype(mask_c)::value;
-      constexpr bool FIRST = decltype(first_c)::value;  // step 0: there is no tile t-1
-      if (wave == ST) make_tab(t + 4, ST);
-      constexpr int KS = ((ST + 1) & 3) * kF8KTile;            // K of tile t+1
-      constexpr int VS = kF8VOff + ((ST + 3) & 3) * kF8KTile;  // V of tile t-1
-      constexpr int KD = ((ST + 3) & 3) * kF8KTile;            // DMA target: K of tile t+3
-      constexpr int VD = kF8VOff + ((ST + 2) & 3) * kF8KTile;  // DMA target: V of tile t+2
-      int unit = 0x7F7F7F7F;
-      asm volatile("" : "+v"(unit));
-      // row offsets of the DMA rows (rows st_row and st_row + 32 of the tables of tiles t+3 and t+2)
-      const u32x4 ok = lds_2xb64_rows32<((ST + 3) & 3) * kTileKV * 8>(tab_rd);
-      const u32x4 ov = lds_2xb64_rows32<((ST + 2) & 3) * kTileKV * 8>(tab_rd);
-      u32x4 ka0, ka1, kb0, kb1;
-      i32x2 va[4], vb[4];
-#define FI_LG_KREAD(lo, hi, I)                                   \
-  lo = lds_b128<KS + ((I) >> 1) * KBLK>(k_rd[(I) & 1][0]);       \
-  hi = lds_b128<KS + ((I) >> 1) * KBLK>(k_rd[(I) & 1][1]);
-#define FI_LG_VREAD(dst, db)                        \
-  if constexpr (!FIRST) {                           \
-    dst[0] = lds_tr8<VS + 0 * TRR>(v_rd[db]);       \
-    dst[1] = lds_tr8<VS + 1 * TRR>(v_rd[db]);       \
-    dst[2] = lds_tr8<VS + 2 * TRR>(v_rd[db]);       \
-    dst[3] = lds_tr8<VS + 3 * TRR>(v_rd[db]);       \
-  }
-#define FI_LG_KWAIT(n, nf, lo, hi)                                                          \
-  if constexpr (FIRST) asm volatile("s_waitcnt lgkmcnt(" #nf ")" : "+v"(lo), "+v"(hi));     \
-  else asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(lo), "+v"(hi));
-#define FI_LG_VWAIT(n, w) \
-  if constexpr (!FIRST) asm volatile("s_waitcnt lgkmcnt(" #n ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]));
-#define FI_LG_KFRAG(lo, hi) \
-  (i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]})
-#define FI_LG_VFRAG(w) (i32x8{w[0][0], w[0][1], w[1][0], w[1][1], w[2][0], w[2][1], w[3][0], w[3][1]})
-#define FI_LG_QK0(dst, lo, hi, b) \
-  if (!(FI_PF8_KO & 16)) { const i32x8 kf = FI_LG_KFRAG(lo, hi); mfma_fp8_k64_asm_zero<BF8>(dst, kf, b, unit); }
-#define FI_LG_QK1(dst, lo, hi, b) \
-  if (!(FI_PF8_KO & 16)) { const i32x8 kf = FI_LG_KFRAG(lo, hi); mfma_fp8_k64_asm<BF8>(dst, kf, b, unit); }
-#define FI_LG_PV(dst, w)                                                                            \
-  if constexpr (!FIRST) {                                                                           \
-    if (!(FI_PF8_KO & 8)) { const i32x8 vf = FI_LG_VFRAG(w); mfma_fp8_k64_asm<BF8>(dst, vf, pp, unit); } \
-  }
-      // half an exp2 chunk: scores R0 .. R0 + 3 of block S -> their sum and one word of the P.V B operand; the empty
-      // asm statements keep the conversions in this gap (the compiler otherwise sinks them below the rare-path branch,
-      // which keeps 32 exp2 results alive)
-#define FI_LG_EXP(S, i) ((FI_PF8_KO & 1) ? exp_arg(S[i]) : fast_exp2(exp_arg(S[i])))
-#define FI_LG_HALF(S, R0, W, HS)                                                                        \
-  {                                                                                                     \
-    const float x0 = FI_LG_EXP(S, R0), x1 = FI_LG_EXP(S, R0 + 1), x2 = FI_LG_EXP(S, R0 + 2), x3 = FI_LG_EXP(S, R0 + 3); \
-    HS = (x0 + x1) + (x2 + x3);                                                                         \
-    int u_;                                                                                             \
-    asm volatile("" : "=v"(u_));                                                                        \
-    if constexpr (BF8) W = __builtin_amdgcn_cvt_pk_bf8_f32(x2, x3, __builtin_amdgcn_cvt_pk_bf8_f32(x0, x1, u_, false), true); \
-    else W = __builtin_amdgcn_cvt_pk_fp8_f32(x2, x3, __builtin_amdgcn_cvt_pk_fp8_f32(x0, x1, u_, false), true);             \
-    asm volatile("" : "+v"(W), "+v"(HS));                                                               \
-  }
-      int w0, w1, w2, w3, w4, w5, w6, w7;
-      float h0, h1, h2, h3, h4, h5, h6, h7;
-      // reads in the order of their use:   R1 ka (2)   R2 va (4)   R3 kb (2)   R4 vb (4)
-      FI_LG_KREAD(ka0, ka1, 0)
-      FI_LG_VREAD(va, 0)
-      FI_LG_KREAD(kb0, kb1, 1)
-      FI_LG_VREAD(vb, 1)
-      __builtin_amdgcn_sched_barrier(0);
-      // gap 0: runs under the LDS latency of the first fragments; then the DMA of K (tile t+3) and V (tile t+2)
-      FI_LG_HALF(sc[0], 0, w0, h0)
-      {
-        u32x4 okk = ok, ovv = ov;
-        if constexpr (FIRST) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(okk), "+v"(ovv));
-        else asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(okk), "+v"(ovv));
-        if (!(FI_PF8_KO & 2)) {
-          dma_issue_one(k_thr, KD, ((uint64_t)okk[1] << 32) | okk[0], ((uint64_t)okk[3] << 32) | okk[2]);
-          dma_issue_one(v_thr, VD, ((uint64_t)ovv[1] << 32) | ovv[0], ((uint64_t)ovv[3] << 32) | ovv[2]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_KWAIT(10, 2, ka0, ka1)            // M1: QK^T block 0, k step 0
-      FI_LG_QK0(sn[0], ka0, ka1, q0)
-      FI_LG_KREAD(ka0, ka1, 2)                // R5
-      FI_LG_HALF(sc[0], 4, w1, h1)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_VWAIT(8, va)                      // M2: P.V block 0
-      FI_LG_PV(o_acc[0], va)
-      FI_LG_VREAD(va, 2)                      // R6
-      FI_LG_HALF(sc[0], 8, w2, h2)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_KWAIT(10, 2, kb0, kb1)            // M3: QK^T block 0, k step 1
-      FI_LG_QK1(sn[0], kb0, kb1, q1)
-      FI_LG_KREAD(kb0, kb1, 3)                // R7
-      FI_LG_HALF(sc[0], 12, w3, h3)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_VWAIT(8, vb)                      // M4: P.V block 1
-      FI_LG_PV(o_acc[1], vb)
-      FI_LG_VREAD(vb, 3)                      // R8
-      FI_LG_HALF(sc[1], 0, w4, h4)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_KWAIT(10, 2, ka0, ka1)            // M5: QK^T block 1, k step 0
-      FI_LG_QK0(sn[1], ka0, ka1, q0)
-      FI_LG_HALF(sc[1], 4, w5, h5)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_VWAIT(6, va)                      // M6: P.V block 2
-      FI_LG_PV(o_acc[2], va)
-      FI_LG_HALF(sc[1], 8, w6, h6)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_KWAIT(4, 0, kb0, kb1)             // M7: QK^T block 1, k step 1
-      FI_LG_QK1(sn[1], kb0, kb1, q1)
-      FI_LG_HALF(sc[1], 12, w7, h7)
-      __builtin_amdgcn_sched_barrier(0);
-      FI_LG_VWAIT(0, vb)                      // M8: P.V block 3
-      FI_LG_PV(o_acc[3], vb)
-      if (FI_PF8_KO & 16) asm volatile("" : "+v"(ka0), "+v"(ka1), "+v"(kb0), "+v"(kb1));
-      if constexpr (!FIRST) {
-        if (FI_PF8_KO & 8) asm volatile("" :: "v"(pp), "v"(va[0]), "v"(vb[0]));
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      float cs0 = h0 + h1, cs1 = h2 + h3, cs2 = h4 + h5, cs3 = h6 + h7;
-      if (__builtin_expect(!(FI_PF8_KO & 32) && __any(!(fmaxf(fmaxf(cs0, cs1), fmaxf(cs2, cs3)) <= kPMax)), 0)) {
-        // rare: some probability may have left the e4m3 range.  The P.V MFMAs of tile t-1 (formed against the old
-        // exponent) are all issued; the s_nops cover their result latency (asm MFMAs are not padded by the compiler)
-        // before O is rescaled.  Then the exact maximum of tile t, the new exponent, and the tile's probabilities again.
-        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                     : "+v"(o_acc[0]), "+v"(o_acc[1]), "+v"(o_acc[2]), "+v"(o_acc[3]));
-        rescale_to(fmaxf(m_run, row_max(sc) * c_exp));
-        FI_LG_HALF(sc[0], 0, w0, h0)
-        FI_LG_HALF(sc[0], 4, w1, h1)
-        FI_LG_HALF(sc[0], 8, w2, h2)
-        FI_LG_HALF(sc[0], 12, w3, h3)
-        FI_LG_HALF(sc[1], 0, w4, h4)
-        FI_LG_HALF(sc[1], 4, w5, h5)
-        FI_LG_HALF(sc[1], 8, w6, h6)
-        FI_LG_HALF(sc[1], 12, w7, h7)
-        cs0 = h0 + h1, cs1 = h2 + h3, cs2 = h4 + h5, cs3 = h6 + h7;
-      }
-      l_run += (cs0 + cs1) + (cs2 + cs3);
-      pn = i32x8{w0, w1, w2, w3, w4, w5, w6, w7};
-      if constexpr (MASK) {
-        // the scores of tile t+1 come from asm MFMAs: cover the result latency of the last one by hand
-        asm volatile("s_nop 15\n\ts_nop 15" : "+v"(sn[0]), "+v"(sn[1]));
-        apply_mask(t + 1, sn);
-      }
-#undef FI_LG_KREAD
-#undef FI_LG_VREAD
-#undef FI_LG_KWAIT
-#undef FI_LG_VWAIT
-#undef FI_LG_KFRAG
-#undef FI_LG_VFRAG
-#undef FI_LG_QK0
-#undef FI_LG_QK1
-#undef FI_LG_PV
-#undef FI_LG_EXP
-#undef FI_LG_HALF
-      if (!(FI_PF8_KO & 4)) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
     auto refill_if_needed = [&](int t_first, int t_last) {
       if (p.kv_indices && !(ids_cover(t_first + 4) && ids_cover(t_last + 4))) {  // uniform; rare
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -829,54 +625,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     int n_plain = 0;
     while (n_plain + 1 < num_tiles && !tile_needs_mask(n_plain + 1)) ++n_plain;
     const int bulk_end = n_plain & ~3;  // four plain steps per trip
-    if constexpr (LAG) {
-      // step t reads S[t & 1] and P[(t - 1) & 1], writes S[(t + 1) & 1] and P[t & 1] (S[0] = s_a, P[0] = pa)
-      i32x8 pa = {0, 0, 0, 0, 0, 0, 0, 0}, pb = {0, 0, 0, 0, 0, 0, 0, 0};
-      refill_if_needed(0, 0);
-      lag_step(integral_constant<int, 0>{}, true_type{}, true_type{}, s_a, s_b, pb, pa, 0);
-      int t = 1;
-      for (; t + 4 <= n_plain; t += 4) {  // steps 1 .. n_plain - 1 need no mask code
-        refill_if_needed(t, t + 3);
-        lag_step(integral_constant<int, 1>{}, false_type{}, false_type{}, s_b, s_a, pa, pb, t);
-        lag_step(integral_constant<int, 2>{}, false_type{}, false_type{}, s_a, s_b, pb, pa, t + 1);
-        lag_step(integral_constant<int, 3>{}, false_type{}, false_type{}, s_b, s_a, pa, pb, t + 2);
-        lag_step(integral_constant<int, 0>{}, false_type{}, false_type{}, s_a, s_b, pb, pa, t + 3);
-      }
-      for (; t < num_tiles; t += 4) {  // t = 1 (mod 4): the stages stay compile-time constants
-        refill_if_needed(t, t + 3);
-        lag_step(integral_constant<int, 1>{}, true_type{}, false_type{}, s_b, s_a, pa, pb, t);
-        if (t + 1 < num_tiles) lag_step(integral_constant<int, 2>{}, true_type{}, false_type{}, s_a, s_b, pb, pa, t + 1);
-        if (t + 2 < num_tiles) lag_step(integral_constant<int, 3>{}, true_type{}, false_type{}, s_b, s_a, pa, pb, t + 2);
-        if (t + 3 < num_tiles) lag_step(integral_constant<int, 0>{}, true_type{}, false_type{}, s_a, s_b, pb, pa, t + 3);
-      }
-      // drain: P.V of the last tile (its V landed two steps ago; the clamped extra tiles still land in the ring)
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-      {
-        const bool odd = (num_tiles - 1) & 1;
-        i32x8 pl;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pl[i] = odd ? pb[i] : pa[i];
-        const int vs = kF8VOff + ((num_tiles - 1) & 3) * kF8KTile;
-        int unit = 0x7F7F7F7F;
-        asm volatile("" : "+v"(unit));
-        i32x2 vf[4][4];
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          vf[db][0] = lds_tr8<0 * TRR>(v_rd[db] + vs);
-          vf[db][1] = lds_tr8<1 * TRR>(v_rd[db] + vs);
-          vf[db][2] = lds_tr8<2 * TRR>(v_rd[db] + vs);
-          vf[db][3] = lds_tr8<3 * TRR>(v_rd[db] + vs);
-        }
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[db][0]), "+v"(vf[db][1]), "+v"(vf[db][2]), "+v"(vf[db][3]));
-          const i32x8 f = {vf[db][0][0], vf[db][0][1], vf[db][1][0], vf[db][1][1], vf[db][2][0], vf[db][2][1], vf[db][3][0], vf[db][3][1]};
-          mfma_fp8_k64_asm<BF8>(o_acc[db], f, pl, unit);
-        }
-      }
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
-                   : "+v"(o_acc[0]), "+v"(o_acc[1]), "+v"(o_acc[2]), "+v"(o_acc[3]));
-    } else {
     // page-id window: the first step whose table (tile t + 4) leaves the window, checked once per trip
     int t = 0;
     for (; t < bulk_end; t += 4) {
@@ -898,7 +646,6 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     // the clamped extra tiles still land in the ring; the s_nops cover the last P.V MFMAs (asm statements: the
     // compiler does not pad their result latency) before the epilogue reads the accumulators
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-    }
   }
 
   // ---- finalize: l_run carries the constant factor of P8, so O / l_run is free of it ----

@@ -72,6 +72,41 @@ def test_group_gemm_fp8_nt_groupwise(ms, n, k, mode):
     torch.testing.assert_close(out.float().cpu(), ref.float(), atol=1e-2, rtol=1e-2)
 
 
+@pytest.mark.parametrize("scales", ["arbitrary", "one_not_pow2", "subnormal_and_huge"])
+@pytest.mark.parametrize("mode", ["MN", "K"])
+def test_group_gemm_scales_that_are_not_powers_of_two(scales, mode):
+    """The reference takes any f32 scale (csrc/group_gemm_fp8_groupwise_sm100.cu:89-124); its own quantiser happens to
+    produce powers of two (flashinfer/testing/utils.py:96-98).  The 256 x 256 kernel feeds power-of-two scales to the
+    MFMA's hardware block scales and must fall back to the general fold when a single scale is not one -- checked on
+    the device, per call.  (tests/test_gemm_variants_gpu.py sends this case through every large-problem kernel.)"""
+    import flashinfer
+
+    torch.manual_seed(5)
+    ms, n, k = [260, 4, 512], 512, 512
+    g, cum = len(ms), sum(ms)
+    a8 = torch.randn(cum, k).to(torch.float8_e4m3fn)
+    b8 = (torch.randn(g, n, k) / math.sqrt(k)).to(torch.float8_e4m3fn)
+    if scales == "arbitrary":
+        sa = torch.rand(k // 128, cum) + 0.5
+        sb = torch.rand(g, k // 128, n // 128) + 0.5
+    elif scales == "one_not_pow2":
+        sa = torch.pow(2.0, torch.randint(-3, 4, (k // 128, cum)).float())
+        sb = torch.pow(2.0, torch.randint(-3, 4, (g, k // 128, n // 128)).float())
+        sb[2, 3, 1] = 0.75
+    else:  # powers of two, but outside what an E8M0 byte of a NORMAL f32 holds, or not positive: no hardware path
+        sa = torch.pow(2.0, torch.randint(-3, 4, (k // 128, cum)).float())
+        sb = torch.pow(2.0, torch.randint(-3, 4, (g, k // 128, n // 128)).float())
+        sa[1, 7] = 2.0 ** -130   # subnormal f32
+        sa[2, 300] = -2.0        # negative
+    if mode == "K":
+        sa, sb = sa.t().contiguous(), sb.transpose(1, 2).contiguous()
+    m_indptr = torch.tensor([0] + list(torch.tensor(ms).cumsum(0)), dtype=torch.int32)
+    out = flashinfer.group_gemm_fp8_nt_groupwise(a8.to(DEV), b8.to(DEV), sa.to(DEV), sb.to(DEV), m_indptr.to(DEV),
+                                                 scale_major_mode=mode)
+    ref = G.group_gemm_fp8_nt_groupwise_ref(a8, b8, sa, sb, m_indptr, mode)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), atol=1e-2, rtol=1e-2)
+
+
 def test_group_gemm_exact_small_integers():
     """Known-answer: small-integer operands and power-of-two scales are exact in fp8 x fp8 -> f32, so the
     kernel must reproduce the integer result bit for bit (catches operand-layout / k-order mistakes that a
