@@ -388,6 +388,7 @@ extern "C" FI_API int fi_batch_prefill_paged_run(void* float_ws, size_t float_ws
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
+  kp.bf16_pv_mode = a->bf16_pv_mode;
   kp.tile_q = (int32_t)plan_info[FI_PP_CTA_TILE_Q];
   const bool fp8_native = use_fp8_native(kp, a->q_dtype, kv.dtype, kv.head_dim, a->pos_encoding_mode == FI_POS_ROPE_LLAMA);
   FI_REQUIRE(kp.tile_q == kTileQ || fp8_native,
@@ -474,6 +475,7 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
   kp.sm_scale = a->sm_scale;
   kp.rope_rcp_scale = a->rope_rcp_scale;
   kp.rope_rcp_theta = a->rope_rcp_theta;
+  kp.bf16_pv_mode = a->bf16_pv_mode;
   // split the kv axis when the q tiles alone cannot fill the chip and the caller lent a scratch buffer
   // (same search as the batch planner; ref: PrefillBinarySearchKVChunkSize, scheduler.cuh:101-130)
   if (tmp && tmp_bytes > 0 && a->mask_mode != FI_MASK_CUSTOM) {

@@ -54,8 +54,11 @@ hipError_t FI_LAUNCHER(const PrefillKernelParams& p, int rope, hipStream_t strea
     const char* s1 = getenv("FI_PREFILL_BF16_SINGLE_P");
     return (s1 && atoi(s1) != 0) ? 0 : 2;
   }();
-  if (pmode == 2) return launch_features<2>(p, rope, stream);
-  if (pmode == 1) return launch_features<1>(p, rope, stream);
+  // the caller's choice (fi_batch_prefill_params_t.bf16_pv_mode: 1 hi + lo, 2 f16 P.V, 3 single rounding) wins over
+  // the process-wide default
+  const int mode = p.bf16_pv_mode == 1 ? 1 : p.bf16_pv_mode == 2 ? 2 : p.bf16_pv_mode == 3 ? 0 : pmode;
+  if (mode == 2) return launch_features<2>(p, rope, stream);
+  if (mode == 1) return launch_features<1>(p, rope, stream);
 #endif
   return launch_features<0>(p, rope, stream);
 }

@@ -81,6 +81,7 @@ struct PrefillKernelParams {
   int32_t o_dtype;      // FI_DTYPE_F16 / BF16
   int32_t fp8_p_quant;  // round P through e4m3 (fp8 Q path)
   int32_t tile_q;       // packed query rows per workgroup the plan was cut for (128; 256: fp8-native 8-wave form)
+  int32_t bf16_pv_mode;  // fi_batch_prefill_params_t.bf16_pv_mode (host-side kernel choice only)
   float logits_soft_cap;
   float sm_scale;
   float rope_rcp_scale, rope_rcp_theta;
@@ -530,12 +531,17 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       if constexpr (KV_FP8) {
         vw = fp8x8_to_16<TPV, KVS>(u32x2{st.r[ps][0], st.r[ps][1]});
       } else if constexpr (PV_F16) {
-        // bf16 -> f16: exact inside f16's range (8 significant bits fit 11), saturating at 65504 beyond it
+        // bf16 -> f16, round to nearest even (v_cvt_pk_f16_f32): exact for 2^-14 <= |v| < 65504 (8 significant bits
+        // fit 11); below that the value lands in f16's subnormal range and loses low bits (unbiased; relative 2^-10 at
+        // 6e-5 growing to 2^-1 at 6e-8); |v| >= 65520 becomes +-inf, NOT a finite clamp -- the wrapper / plan option
+        // `bf16_pv_exact_range=True` (hi + lo bf16 P on the bf16 MFMA, no range limit) is for caches that hold such
+        // values
+        typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
           const uint32_t raw = st.r[ps][w];
-          const auto h2 = __builtin_amdgcn_cvt_pkrtz(__builtin_bit_cast(float, raw << 16),
-                                                     __builtin_bit_cast(float, raw & 0xffff0000u));
+          const f16x2_t h2 = {(_Float16)__builtin_bit_cast(float, raw << 16),
+                              (_Float16)__builtin_bit_cast(float, raw & 0xffff0000u)};
           vw[w] = __builtin_bit_cast(uint32_t, h2);
         }
       } else {
@@ -734,6 +740,10 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       // the stale m_run and may reach 2^kRescaleLog2 -- exact power-of-two scaling, cancelled by l_run.
       // Not used when P is rounded to e4m3 (fp8 q): that needs P <= 1.
       constexpr float kRescaleLog2 = Q_FP8 ? 0.f : 6.f;
+      // PV_F16: P enters the f16 MFMA; it is formed 2^9 up (P <= 2^6 * 2^9 = 2^15 < 65504), so probabilities down to
+      // 2^-23 of the reference exponent stay NORMAL f16 numbers (unscaled, everything below 6e-5 would lose bits in
+      // f16's subnormal range).  The row sum carries the same factor: O / l is free of it, the lse subtracts it.
+      constexpr float kPShift = PV_F16 ? 9.f : 0.f;
       const float m_true = fmaxf(m_run, mx * c_log2);  // c_log2 > 0
       if (__any(m_true - m_run > kRescaleLog2)) {
         const float alpha = fast_exp2(m_run - m_true);
@@ -749,7 +759,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, -m_run));
+          s_acc[kbk][r] = fast_exp2(__builtin_fmaf(s_acc[kbk][r], c_log2, kPShift - m_run));
           psum += s_acc[kbk][r];
         }
       l_run += psum;
@@ -841,7 +851,8 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
                                              o_acc[db][4 * r4 + 2] * inv, o_acc[db][4 * r4 + 3] * inv};
       }
     }
-    if (lh == 0) p.tmp_lse[entry * p.num_qo_heads + qo_head] = empty ? FI_NEG_INF : m_run + fast_log2(l_run);
+    if (lh == 0)
+      p.tmp_lse[entry * p.num_qo_heads + qo_head] = empty ? FI_NEG_INF : m_run + fast_log2(l_run) - (PV_F16 ? 9.f : 0.f);
   } else if (row_valid) {
     const int64_t ob = ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D;
 #pragma unroll
@@ -857,7 +868,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     }
     if (p.lse && lh == 0)
       p.lse[(int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head] =
-          empty ? FI_NEG_INF : m_run + fast_log2(l_run);
+          empty ? FI_NEG_INF : m_run + fast_log2(l_run) - (PV_F16 ? 9.f : 0.f);
   }
 }
 

@@ -130,6 +130,7 @@ class BatchPrefillParams(C.Structure):
         ("sm_scale", C.c_float),
         ("rope_rcp_scale", C.c_float),
         ("rope_rcp_theta", C.c_float),
+        ("bf16_pv_mode", C.c_int32),
     ]
 
 
@@ -164,6 +165,7 @@ class SinglePrefillParams(C.Structure):
         ("sm_scale", C.c_float),
         ("rope_rcp_scale", C.c_float),
         ("rope_rcp_theta", C.c_float),
+        ("bf16_pv_mode", C.c_int32),
     ]
 
 

@@ -140,6 +140,20 @@ def get_batch_prefill_module(backend, dtype_q, dtype_kv, dtype_o, idtype, head_d
                 float_ws.data_ptr(), _nbytes(float_ws), int_ws.data_ptr(), _nbytes(int_ws), info,
                 _lib.FI_PREFILL_PLAN_INFO_LEN, C.byref(p), _stream(q)), what)
 
+    def _tail16(additional):
+        """additional parameters of a 16-bit-q call, normalised to the fa2 order.  The reference's fa3 (Hopper)
+        specialisation passes SIX: maybe_prefix_len_ptr, maybe_token_pos_in_items_ptr, maybe_max_item_len_ptr,
+        logits_soft_cap, sm_scale, token_pos_in_items_len (flashinfer/prefill.py:624-646) -- no custom mask, ALiBi or
+        fused RoPE there; fa2 passes eleven (prefill.py:604-622)."""
+        if len(additional) == 6:
+            prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, logits_soft_cap, sm_scale, tp_len = additional
+            return (None, None, None, prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, logits_soft_cap,
+                    sm_scale, 1.0, 1e-4, tp_len)
+        if len(additional) != 11:
+            raise ValueError(f"batch_prefill run: {len(additional)} additional parameters; the fa2 form has 11, "
+                             f"the fa3 form 6, the fp8 form 4")
+        return additional
+
     def paged_run(float_workspace_buffer, int_workspace_buffer, plan_info_vec, q, paged_k_cache, paged_v_cache,
                   qo_indptr, paged_kv_indptr, paged_kv_indices, paged_kv_last_page_len, o, maybe_lse, mask_mode_code,
                   layout, window_left, enable_pdl, *additional) -> None:
@@ -158,7 +172,7 @@ def get_batch_prefill_module(backend, dtype_q, dtype_kv, dtype_o, idtype, head_d
                  1.0, 1e-4, scale_q, scale_k, scale_v, "batch_prefill.paged_run(fp8)")
         else:
             (custom_mask, mask_indptr, alibi_slopes, prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr,
-             logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta, token_pos_in_items_len) = additional
+             logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta, token_pos_in_items_len) = _tail16(additional)
             _run(float_workspace_buffer, int_workspace_buffer, plan_info_vec, q, paged_k_cache, paged_v_cache, qo_indptr,
                  kv, o, maybe_lse, mask_mode_code, window_left, custom_mask, mask_indptr, alibi_slopes, prefix_len_ptr,
                  token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len, logits_soft_cap, sm_scale,
@@ -176,7 +190,7 @@ def get_batch_prefill_module(backend, dtype_q, dtype_kv, dtype_o, idtype, head_d
             num_kv_heads=k.shape[1 if nhd else 0], head_dim=k.shape[2], batch_size=kv_indptr.shape[0] - 1,
             dtype=_lib.fi_dtype(k.dtype))
         (custom_mask, mask_indptr, alibi_slopes, prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr,
-         logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta, token_pos_in_items_len) = additional
+         logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta, token_pos_in_items_len) = _tail16(additional)
         _run(float_workspace_buffer, int_workspace_buffer, plan_info_vec, q, k, v, qo_indptr, kv, o, maybe_lse,
              mask_mode_code, window_left, custom_mask, mask_indptr, alibi_slopes, prefix_len_ptr,
              token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len, logits_soft_cap, sm_scale,

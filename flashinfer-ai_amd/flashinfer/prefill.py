@@ -81,10 +81,26 @@ def _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_
         raise ValueError("max_item_len_ptr must be uint16")
     if prefix_len_ptr.numel() != batch_size:
         raise ValueError("prefix_len_ptr must have one entry per request")
-    if token_pos_in_items_len <= 0 or token_pos_in_items_ptr.numel() < (batch_size - 1) * token_pos_in_items_len + 1:
+    if token_pos_in_items_len <= 0 or token_pos_in_items_ptr.numel() < batch_size * token_pos_in_items_len:
         raise ValueError("token_pos_in_items_ptr is shorter than batch_size rows of token_pos_in_items_len")
     return (prefix_len_ptr.to(device).contiguous(), token_pos_in_items_ptr.to(device).contiguous(),
             None if max_item_len_ptr is None else max_item_len_ptr.to(device).contiguous(), int(token_pos_in_items_len))
+
+
+def _check_multi_item_rows(prefix_len_ptr, token_pos_in_items_len, kv_lens_host):
+    """The kernel reads token_pos_in_items[b][q_pos - prefix_len[b]] for every query position past the prefix, i.e. up
+    to kv_len[b] - prefix_len[b] entries of row b: a shorter row would read the next request's row (or past the
+    buffer) and the mask would be silently wrong.  plan() holds the kv lengths on the host; the prefix lengths come
+    back with one small copy (plan() is synchronous host code anyway, ref: prefill.py:1547-1558)."""
+    if prefix_len_ptr is None:
+        return
+    prefix = prefix_len_ptr.to("cpu").to(torch.int64)
+    need = kv_lens_host.to(torch.int64) - prefix
+    if bool((need > token_pos_in_items_len).any()):
+        b = int(torch.nonzero(need > token_pos_in_items_len)[0])
+        raise ValueError(
+            f"multi-item scoring: request {b} has kv_len - prefix_len = {int(need[b])} positions past its prefix but "
+            f"token_pos_in_items_len is {token_pos_in_items_len}")
 
 
 def _mask_mode(wrapper) -> int:
@@ -156,6 +172,7 @@ def single_prefill_with_kv_cache(
     rope_theta: Optional[float] = None,
     backend: str = "auto",
     return_lse: bool = False,
+    bf16_pv_exact_range: bool = False,
 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
     r"""Prefill / append attention with KV cache for a single request.
 
@@ -169,6 +186,9 @@ def single_prefill_with_kv_cache(
     pos_encoding_mode : ``NONE`` / ``ROPE_LLAMA`` (applied in-kernel) / ``ALIBI``
     sm_scale, window_left, logits_soft_cap, rope_scale, rope_theta : as the reference
     return_lse : also return the base-2 logsumexp, shape ``[qo_len, num_qo_heads]``
+    bf16_pv_exact_range : (extension, bf16 queries) ``True`` when ``v`` may hold ``|v| >= 65504`` or many
+        ``|v| < 6e-5``: the kernel then keeps V in bf16 and enters P as hi + lo bf16 halves (about 25 % slower)
+        instead of running P.V on the f16 matrix cores, whose V operand is exact only inside f16's normal range
 
     custom_mask : ``[qo_len, kv_len]`` bool; packed_custom_mask : its ``packbits(..., bitorder="little")``
         form (takes precedence).  With a mask, ``causal`` is ignored (mask mode CUSTOM).
@@ -235,7 +255,7 @@ def single_prefill_with_kv_cache(
                    else MaskMode.CAUSAL.value if causal else MaskMode.NON_CAUSAL.value),
         pos_encoding_mode=PosEncodingMode[pos_encoding_mode].value, window_left=window_left,
         logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
-        rope_rcp_theta=1.0 / rope_theta,
+        rope_rcp_theta=1.0 / rope_theta, bf16_pv_mode=1 if bf16_pv_exact_range else 0,
     )
     # scratch for split-KV partial states (ref: the 32 MB cached buffer of single_prefill, prefill.py:1125)
     tmp = _get_cache_buf("single_prefill_with_kv_cache_tmp", 32 * 1024 * 1024, q.device)
@@ -366,6 +386,7 @@ class BatchPrefillWithPagedKVCacheWrapper:
         fixed_split_size: Optional[int] = None,
         disable_split_kv: bool = False,
         o_data_type: Optional[Union[str, torch.dtype]] = None,
+        bf16_pv_exact_range: bool = False,
     ) -> None:
         r"""Plan batch prefill/append attention for the given ragged queries and page table.
 
@@ -373,6 +394,9 @@ class BatchPrefillWithPagedKVCacheWrapper:
         causal, pos_encoding_mode, sm_scale, window_left, logits_soft_cap, rope_* configure the variant.
         q_data_type / kv_data_type : dtypes the run() tensors will have (fp8 e4m3 for both = fp8 attention).
         o_data_type : (extension) output dtype; defaults to the q dtype, or bfloat16 for fp8 queries.
+        bf16_pv_exact_range : (extension, bf16 queries) the cache may hold ``|v| >= 65504`` or many ``|v| < 6e-5``:
+            P.V then runs with hi + lo bf16 probabilities instead of on the f16 matrix cores (no range limit on V,
+            about 25 % slower); see :func:`single_prefill_with_kv_cache`.
         custom_mask : flattened bool mask, request i contributes ``qo_len[i] * kv_len[i]`` entries
             (row-major ``[qo_len, kv_len]``); packed_custom_mask : its ``segment_packbits(..., "little")`` form.
             With a mask the mask mode is CUSTOM and ``causal`` is ignored (ref: prefill.py:1693-1706, 1890-1905).
@@ -382,6 +406,7 @@ class BatchPrefillWithPagedKVCacheWrapper:
         ``causal=True``; ref: prefill.py:1547-1558, 2099-2100, prefill.cuh:795-858).
         (ref: flashinfer/prefill.py:1523-1921)
         """
+        self._bf16_pv_mode = 1 if bf16_pv_exact_range else 0
         self._prefix_len_ptr, self._token_pos_in_items_ptr, self._max_item_len_ptr, self._token_pos_in_items_len = \
             _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len,
                                    len(qo_indptr) - 1, self.device)
@@ -414,6 +439,7 @@ class BatchPrefillWithPagedKVCacheWrapper:
         else:
             kv_lens_arr_host = seq_lens.cpu()
         kv_lens_arr_host = kv_lens_arr_host.to(torch.int32).contiguous()
+        _check_multi_item_rows(self._prefix_len_ptr, self._token_pos_in_items_len, kv_lens_arr_host)
         total_num_rows = int(qo_indptr_host[-1])
         self._custom_mask_buf, self._mask_indptr_buf = _plan_custom_mask(
             self, custom_mask, packed_custom_mask, qo_indptr_host, kv_lens_arr_host, non_blocking)
@@ -609,7 +635,7 @@ class BatchPrefillWithPagedKVCacheWrapper:
             mask_mode=_mask_mode(self),
             pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=window_left,
             logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
-            rope_rcp_theta=1.0 / rope_theta,
+            rope_rcp_theta=1.0 / rope_theta, bf16_pv_mode=getattr(self, "_bf16_pv_mode", 0),
         )
         with torch.cuda.device(q.device):
             _lib.check(
@@ -737,9 +763,11 @@ class BatchPrefillWithRaggedKVCacheWrapper:
         max_item_len_ptr: Optional[torch.Tensor] = None,
         fixed_split_size: Optional[int] = None,
         disable_split_kv: bool = False,
+        bf16_pv_exact_range: bool = False,
     ) -> None:
         r"""Plan for ragged queries ``qo_indptr`` and ragged keys/values ``kv_indptr`` (both int32
         ``[batch_size + 1]``).  Options as :meth:`BatchPrefillWithPagedKVCacheWrapper.plan`."""
+        self._bf16_pv_mode = 1 if bf16_pv_exact_range else 0
         self._prefix_len_ptr, self._token_pos_in_items_ptr, self._max_item_len_ptr, self._token_pos_in_items_len = \
             _check_multi_item_args(prefix_len_ptr, token_pos_in_items_ptr, max_item_len_ptr, token_pos_in_items_len,
                                    len(qo_indptr) - 1, self.device)
@@ -761,6 +789,7 @@ class BatchPrefillWithRaggedKVCacheWrapper:
         qo_indptr_host = qo_indptr.to("cpu").contiguous()
         kv_indptr_host = kv_indptr.to("cpu").contiguous()
         kv_len_arr = (kv_indptr_host[1:] - kv_indptr_host[:-1]).to(torch.int32).contiguous()
+        _check_multi_item_rows(self._prefix_len_ptr, self._token_pos_in_items_len, kv_len_arr)
         total_num_rows = int(qo_indptr_host[-1])
         self._custom_mask_buf, self._mask_indptr_buf = _plan_custom_mask(
             self, custom_mask, packed_custom_mask, qo_indptr_host, kv_len_arr, non_blocking)
@@ -882,7 +911,7 @@ class BatchPrefillWithRaggedKVCacheWrapper:
             mask_mode=_mask_mode(self),
             pos_encoding_mode=PosEncodingMode[self._pos_encoding_mode].value, window_left=self._window_left,
             logits_soft_cap=logits_soft_cap, sm_scale=sm_scale, rope_rcp_scale=1.0 / rope_scale,
-            rope_rcp_theta=1.0 / rope_theta,
+            rope_rcp_theta=1.0 / rope_theta, bf16_pv_mode=getattr(self, "_bf16_pv_mode", 0),
         )
         with torch.cuda.device(q.device):
             _lib.check(

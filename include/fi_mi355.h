@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FI_ABI_VERSION 1
+#define FI_ABI_VERSION 2
 #define FI_NEG_INF (-5.0e4f)
 
 typedef void* fi_stream_t; /* hipStream_t */
@@ -282,6 +282,12 @@ typedef struct fi_batch_prefill_params {
   int32_t pos_encoding_mode;
   int32_t window_left;
   float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
+  /* bf16 queries only -- how the probabilities enter P.V (csrc/prefill_kernel.h, PMODE): 0 default = P.V on the f16
+   * MFMA (P rounded to f16, V converted bf16 -> f16 while staged: exact for 2^-14 <= |v| < 65504, the result meets the
+   * reference's 1e-3 bar); 1 = P as hi + lo bf16 halves on the bf16 MFMA (no range limit on V; ~25 % slower) -- for
+   * caches that may hold |v| >= 65504 or many |v| < 6e-5; 2 = the default, explicitly; 3 = the reference's single bf16
+   * rounding of P (prefill.cuh:962-985).  Ignored for other q dtypes. */
+  int32_t bf16_pv_mode;
 } fi_batch_prefill_params_t;
 
 /* Ragged (non-paged) KV, ref BatchPrefillWithRaggedKVCacheRun csrc/batch_prefill.cu:76-197: pass the
@@ -309,6 +315,7 @@ typedef struct fi_single_prefill_params {
   int32_t q_dtype, kv_dtype, o_dtype;
   int32_t mask_mode, pos_encoding_mode, window_left;
   float logits_soft_cap, sm_scale, rope_rcp_scale, rope_rcp_theta;
+  int32_t bf16_pv_mode; /* as fi_batch_prefill_params_t.bf16_pv_mode */
 } fi_single_prefill_params_t;
 
 FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* params, void* tmp, size_t tmp_bytes,

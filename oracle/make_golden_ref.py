@@ -23,6 +23,8 @@ import ast
 import math
 import os
 
+import builtins
+
 import einops
 import numpy as np
 import torch
@@ -35,7 +37,22 @@ def load_functions(rel_path, names, patch=None):
     """Compile the named top-level functions of a reference file into a fresh namespace."""
     src = open(os.path.join(REF, rel_path)).read()
     tree = ast.parse(src)
-    ns = {"torch": torch, "math": math, "Tuple": tuple, "rearrange": einops.rearrange,
+    # The function bodies come from an untrusted tree: they get torch / math / einops and a short whitelist of
+    # builtins -- no open, no __import__, no eval / exec / getattr -- so a changed reference file cannot touch the
+    # build container through this script (ADVICE r2).
+    safe_builtins = {k: getattr(builtins, k) for k in (
+        "range", "len", "int", "float", "bool", "tuple", "list", "dict", "min", "max", "abs", "sum", "zip",
+        "enumerate", "isinstance", "slice", "print", "round", "sorted", "reversed", "map", "any", "all", "str",
+        "ValueError", "AssertionError", "RuntimeError", "TypeError", "NotImplementedError", "Exception",
+        "True", "False", "None")
+        if hasattr(builtins, k)}
+    def _import(name, globals=None, locals=None, fromlist=(), level=0):
+        if level != 0 or name.split(".")[0] not in ("math", "torch", "einops"):
+            raise ImportError(f"import of {name!r} is not allowed in extracted reference functions")
+        return builtins.__import__(name, globals, locals, fromlist, level)
+
+    safe_builtins["__import__"] = _import
+    ns = {"__builtins__": safe_builtins, "torch": torch, "math": math, "Tuple": tuple, "rearrange": einops.rearrange,
           "reduce": einops.reduce, "repeat": einops.repeat, "einsum": einops.einsum}
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(fi_lib):
 
 
 def test_abi_version_and_cu_count(fi_lib):
-    assert fi_lib.fi_abi_version() == 1
+    assert fi_lib.fi_abi_version() == 2
     assert fi_lib.fi_num_compute_units() > 0
 
 

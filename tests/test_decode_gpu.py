@@ -151,6 +151,31 @@ def test_batch_decode_pos_encoding(mode, d):
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=2e-3, atol=2e-3)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_batch_decode_fused_rope_against_f32_rotation_oracle(dtype, d):
+    """the matrix-core decode kernels round the rotated q / k to the 16-bit type (what the reference's
+    tensor-core decode = its prefill kernel does, prefill.cuh:465-612); the reference's DEFAULT decode path rotates
+    and multiplies in f32 (decode.cuh:445-466).  This test measures the distance to THAT arithmetic (oracle without
+    rope_round_dtype) and holds it to a stated, looser bar: the rounding of q and k perturbs every logit by about
+    2^-11 (fp16) / 2^-8 (bf16) of |q||k|/sqrt(d), which moves the output by up to ~2e-3 (fp16) / ~1.5e-2 (bf16) of the
+    value scale -- recorded in INTEGRATION.md as a known difference from the reference's non-tensor-core decode."""
+    hq, hkv, page_size = 8, 2, 16
+    kv_lens = [54, 700, 1, 2049]
+    torch.manual_seed(15)
+    cache, indptr, indices, last = make_paged(len(kv_lens), kv_lens, page_size, hkv, d, dtype, "NHD", seed=19)
+    q = torch.randn(len(kv_lens), hq, d).to(dtype)
+    (o, lse), _ = run_batch_decode(q, cache, "NHD", indptr, indices, last, hq, hkv, d, page_size,
+                                   pos_encoding_mode="ROPE_LLAMA", rope_theta=1e4, rope_scale=1.0)
+    o_ref, lse_ref = R.batch_decode_ref(q.float(), cache.float(), "NHD", indptr, indices, last,
+                                        pos_encoding_mode="ROPE_LLAMA")  # f32 rotation, no rounding of q / k
+    err = (o.float().cpu() - o_ref.float()).abs().max().item()
+    lerr = (lse.cpu() - lse_ref.float()).abs().max().item()
+    print(f"decode fused RoPE vs f32-rotation oracle, {dtype} d={d}: max |o - ref| {err:.2e}, max |lse - ref| {lerr:.2e}")
+    bar = 4e-3 if dtype == torch.float16 else 3e-2
+    assert err < bar and lerr < bar
+
+
 @pytest.mark.parametrize("window_left,soft_cap", [(15, 0.0), (300, 0.0), (-1, 30.0), (64, 8.0)])
 def test_batch_decode_window_and_soft_cap(window_left, soft_cap):
     hq, hkv, d, page_size = 8, 4, 128, 16

@@ -107,6 +107,59 @@ def test_batch_prefill_module_reference_call_sequence(causal):
     torch.testing.assert_close(out2.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
 
 
+def test_batch_prefill_module_fa3_six_argument_tail():
+    """The reference's fa3 16-bit specialisation calls paged_run / ragged_run with SIX additional parameters
+    (maybe_prefix_len_ptr, maybe_token_pos_in_items_ptr, maybe_max_item_len_ptr, logits_soft_cap, sm_scale,
+    token_pos_in_items_len; flashinfer/prefill.py:624-646) and plans without the fa2-only split arguments."""
+    from flashinfer import compat
+
+    hq, hkv, d, ps = 8, 2, 128, 16
+    kv_lens, qo_lens = [200, 77], [64, 77]
+    b = len(kv_lens)
+    cache, indptr, indices, last = make_paged(b, kv_lens, ps, hkv, d, torch.float16, "NHD", seed=23)
+    torch.manual_seed(2)
+    q = torch.randn(sum(qo_lens), hq, d).half()
+    qo_indptr = torch.tensor([0] + list(torch.tensor(qo_lens).cumsum(0)), dtype=torch.int32)
+    float_ws, int_ws, pinned = _workspaces()
+    mod = compat.get_batch_prefill_module("fa3", torch.float16, torch.float16, torch.float16, torch.int32, d, d, 0,
+                                          False, False, False)
+    plan_info = mod.plan(float_ws, int_ws, pinned, qo_indptr, indptr, torch.tensor(kv_lens, dtype=torch.int32),
+                         int(qo_indptr[-1]), b, hq, hkv, ps, False, d, d, True, -1)
+    cd, qd = cache.to(DEV), q.to(DEV)
+    out = torch.empty_like(qd)
+    mod.paged_run(float_ws, int_ws, plan_info, qd, cd[:, 0], cd[:, 1], qo_indptr.to(DEV), indptr.to(DEV),
+                  indices.to(DEV), last.to(DEV), out, None, 1, 0, -1, False,
+                  None, None, None, 0.0, 1.0 / math.sqrt(d), 0)
+    o_ref, _ = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last, causal=True)
+    torch.testing.assert_close(out.float().cpu(), o_ref.float(), rtol=1e-3, atol=1e-3)
+    with pytest.raises(ValueError):
+        mod.paged_run(float_ws, int_ws, plan_info, qd, cd[:, 0], cd[:, 1], qo_indptr.to(DEV), indptr.to(DEV),
+                      indices.to(DEV), last.to(DEV), out, None, 1, 0, -1, False, None, None, None)
+
+
+def test_multi_item_scoring_rejects_rows_shorter_than_the_queries_past_the_prefix():
+    """the kernel indexes token_pos_in_items[b][q_pos - prefix_len[b]]; a row shorter than
+    kv_len - prefix_len would read the next request's row.  plan() refuses it."""
+    import flashinfer
+
+    hq, hkv, d, ps, b = 4, 4, 128, 16, 2
+    kv_lens, qo_len = [64, 64], 40
+    cache, indptr, indices, last = make_paged(b, kv_lens, ps, hkv, d, torch.float16, "NHD", seed=3)
+    qo_indptr = (torch.arange(b + 1) * qo_len).to(torch.int32)
+    ws = torch.zeros(32 << 20, dtype=torch.uint8, device=DEV)
+    w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, "NHD")
+    kw = dict(causal=True, prefix_len_ptr=torch.tensor([30, 30]).to(torch.uint32).to(DEV))
+    with pytest.raises(ValueError, match="token_pos_in_items_len"):  # 34 positions past the prefix, rows of 20
+        w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps,
+               token_pos_in_items_ptr=torch.zeros(b * 20, dtype=torch.uint16, device=DEV), token_pos_in_items_len=20, **kw)
+    with pytest.raises(ValueError):  # the last row must be whole too: batch * len entries
+        w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps,
+               token_pos_in_items_ptr=torch.zeros(b * 34 - 3, dtype=torch.uint16, device=DEV), token_pos_in_items_len=34,
+               **kw)
+    w.plan(qo_indptr.to(DEV), indptr.to(DEV), indices.to(DEV), last.to(DEV), hq, hkv, d, ps,
+           token_pos_in_items_ptr=torch.zeros(b * 34, dtype=torch.uint16, device=DEV), token_pos_in_items_len=34, **kw)
+
+
 def test_batch_prefill_fp8_module_reference_call_sequence():
     """fa3 fp8 specialisation: plan stops at window_left, paged_run takes (scale_q, scale_k, scale_v, sm_scale)
     (csrc/batch_prefill_fp8_sm90.cu:39-44, 81-90)."""

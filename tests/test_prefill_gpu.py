@@ -552,3 +552,71 @@ def test_fp8_prefill_peaked_rows(f8, d):
     # costs 3 eps ~ 0.066 at most (the e5m2 grid of P is one octave coarser at the same exponent range)
     assert err16 < 0.07
     torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-4, atol=1e-3)
+
+
+def _bf16_single(q, k, v, **kw):
+    import flashinfer
+
+    return flashinfer.single_prefill_with_kv_cache(q.to(DEV), k.to(DEV), v.to(DEV), causal=True, return_lse=True, **kw)
+
+
+@pytest.mark.parametrize("case", ["v_1e-5", "v_1e-6", "logit_spread_20_nats"])
+def test_bf16_prefill_f16_pv_mode_small_values_and_wide_logit_spread(case):
+    """the default bf16 path runs P.V on the f16 MFMA (P rounded to f16, V converted bf16 -> f16
+    while staged).  What could go wrong there and what the kernel does about it:
+      * P below 6e-5 would sit in f16's subnormal range -- P is formed 2^9 up (the row sum carries the same factor),
+        so a 20-nat logit spread (terms down to e^-20 = 2e-9 of the row maximum) keeps its small terms;
+      * |v| < 6.1e-5 lands in f16 subnormals while it is converted (round to nearest even, v_cvt_pk_f16_f32): the
+        relative error grows from 2^-11 at 6e-5 to ~3 % at 1e-6 -- unbiased, so the attention AVERAGE stays far
+        closer; the test states what is measured, with RELATIVE tolerances, against the exact oracle and against the
+        hi + lo mode (`bf16_pv_exact_range=True`), which has no such limit."""
+    torch.manual_seed(12)
+    h, d, qo_len, kv_len = 4, 128, 96, 700
+    q = torch.randn(qo_len, h, d)
+    k = torch.randn(kv_len, h, d)
+    v = torch.randn(kv_len, h, d)
+    if case == "v_1e-5":
+        v = v * 1e-5
+    elif case == "v_1e-6":
+        v = v * 1e-6
+    else:
+        q = q * 2.6  # logits q.k / sqrt(d) ~ N(0, 2.6^2): the row maximum sits ~ 8 sigma = 20 nats over the typical term
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    o, lse = _bf16_single(q, k, v)
+    o_x, lse_x = _bf16_single(q, k, v, bf16_pv_exact_range=True)
+    o_ref, lse_ref = R.attention_ref(q.float(), k.float(), v.float(), causal=True)
+    scale = o_ref.abs().max().item()
+    err = (o.float().cpu() - o_ref.float()).abs().max().item() / scale
+    err_x = (o_x.float().cpu() - o_ref.float()).abs().max().item() / scale
+    print(f"bf16 f16-P.V mode, {case}: max |o - ref| / max |ref| = {err:.2e}  (hi + lo mode {err_x:.2e})")
+    assert torch.isfinite(o.float()).all()
+    # bf16 output rounding alone is 2^-9 = 2e-3 relative to the element; relative to the row scale:
+    assert err_x < 6e-3
+    assert err < (3e-2 if case == "v_1e-6" else 6e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(lse_x.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+
+
+def test_bf16_prefill_values_beyond_f16_range_need_the_exact_range_option():
+    """|v| up to 1e5 (bf16 holds it, f16 does not): with `bf16_pv_exact_range=True` (wrapper plan() / single prefill
+    keyword; C ABI fi_batch_prefill_params_t.bf16_pv_mode = 1) the kernel keeps V in bf16 and the result meets the
+    usual bar; the default f16 P.V mode turns |v| >= 65520 into infinities -- visibly, not a silent clamp (pinned
+    here so that a change of that behaviour is a decision, not an accident; documented in INTEGRATION.md)."""
+    import flashinfer
+
+    torch.manual_seed(13)
+    hq, hkv, d, ps = 8, 2, 128, 16
+    kv_lens, qo_lens = [300, 77], [64, 77]
+    cache, indptr, indices, last = make_paged(2, kv_lens, ps, hkv, d, torch.bfloat16, "NHD", seed=14)
+    cache = cache.float()
+    cache[:, 1] *= 3.0e4  # V ~ N(0, 3e4^2): |v| reaches ~1.2e5
+    cache = cache.bfloat16()
+    q = torch.randn(sum(qo_lens), hq, d).bfloat16()
+    o, lse, qo_indptr = run_batch_prefill(q, qo_lens, cache, "NHD", indptr, indices, last, hq, hkv, d, ps, causal=True,
+                                          bf16_pv_exact_range=True)
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last, causal=True)
+    scale = o_ref.abs().max().item()
+    assert (o.float().cpu() - o_ref.float()).abs().max().item() / scale < 6e-3
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    o_def, _, _ = run_batch_prefill(q, qo_lens, cache, "NHD", indptr, indices, last, hq, hkv, d, ps, causal=True)
+    assert not torch.isfinite(o_def.float()).all()
