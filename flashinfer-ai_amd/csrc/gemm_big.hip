@@ -37,6 +37,9 @@ constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64
 #ifndef FI_GEMM_BIG_BAND
 #define FI_GEMM_BIG_BAND 1024
 #endif
+#ifndef FI_GEMM_BIG_INTERLEAVE
+#define FI_GEMM_BIG_INTERLEAVE 1
+#endif
 #ifndef FI_GEMM_BIG_KO
 #define FI_GEMM_BIG_KO 0  // experiments only, bit mask: 1 no output stores, 2 no fold, 4 no DMA in the k loop
 #endif
@@ -84,18 +87,27 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
   uint32_t a_rd_base = (uint32_t)lds_off(64 * wm + lq, 2 * lh);
   uint32_t b_rd_base = (uint32_t)(kBOff + lds_off(128 * wn + lq, 2 * lh));
 
-  // ---- persistent workgroup: the XCD-contiguous tile range of this XCD, strided by its workgroups ----
+  // ---- persistent workgroup: the tiles of this XCD, strided by its workgroups ----
+  // Tiles are ordered in bands of kBandM m tiles x all n tiles (m fastest inside a band, see gemm.hip).  The bands are
+  // dealt to the 8 XCDs INTERLEAVED: XCD x takes bands x, x + 8, x + 16 ... -- at any time the chip works on 8
+  // CONSECUTIVE bands, i.e. on one or two groups, whose B matrices (C4: 59 MB each) stay in the 256 MB Infinity
+  // Cache while every XCD streams them, instead of eight groups' worth (470 MB) going to HBM each time (r2 gave
+  // XCD x a contiguous tile range, which at C4 is group x for the whole launch).
   const int n_tiles = (N + kBigTN - 1) / kBigTN;
   const int total = p.num_m_tiles_bound * n_tiles;
-  int logical, logical_end;
+  constexpr int kBandM = FI_GEMM_BIG_BAND / kBigTM;  // 1024 rows x all n per band
+  const int band_tiles = kBandM * n_tiles;
+  // whole rounds of 8 bands are dealt one band per XCD; what is left (fewer than 8 bands, the last one possibly
+  // short) is split into contiguous ranges so that every XCD gets the same number of tiles (+- 1)
+  const int n_inter = FI_GEMM_BIG_INTERLEAVE ? (p.num_m_tiles_bound / (8 * kBandM)) * band_tiles : 0;  // per XCD
   const int logical_step = gridDim.x >> 3;
+  const int xcd_id = blockIdx.x & 7;
+  int logical = blockIdx.x >> 3, logical_end, rem_base;
   {
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int qn = total >> 3, rn = total & 7;
-    const int start = xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn;
-    logical = start + slot;
-    logical_end = start + qn + (xcd < rn ? 1 : 0);
+    const int rem_total = total - 8 * n_inter;
+    const int qn = rem_total >> 3, rn = rem_total & 7;
+    rem_base = 8 * n_inter + (xcd_id < rn ? xcd_id * (qn + 1) : rn * (qn + 1) + (xcd_id - rn) * qn);
+    logical_end = n_inter + qn + (xcd_id < rn ? 1 : 0);
   }
 
   // up to 64 groups: group i's row range and first tile live in LDS (a register copy per lane would stay
@@ -166,10 +178,16 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
   };
 
   for (; logical < logical_end; logical += logical_step) {
-    constexpr int kBandM = FI_GEMM_BIG_BAND / kBigTM;  // 1024 rows x all n per band, m fastest (see gemm.hip)
-    const int band_tiles = kBandM * n_tiles;
-    const int band = logical / band_tiles;
-    const int in_band = logical - band * band_tiles;
+    int band, in_band;
+    if (logical < n_inter) {  // the XCD's own band of round band_l
+      const int band_l = logical / band_tiles;
+      in_band = logical - band_l * band_tiles;
+      band = band_l * 8 + xcd_id;
+    } else {
+      const int gl = rem_base + (logical - n_inter);
+      band = gl / band_tiles;
+      in_band = gl - band * band_tiles;
+    }
     const int band_m = min(kBandM, p.num_m_tiles_bound - band * kBandM);
     const int nt = in_band / band_m;
     const int mt_global = band * kBandM + (in_band - nt * band_m);

@@ -159,7 +159,7 @@ def test_batch_decode_fused_rope_against_f32_rotation_oracle(dtype, d):
     and multiplies in f32 (decode.cuh:445-466).  This test measures the distance to THAT arithmetic (oracle without
     rope_round_dtype) and holds it to a stated, looser bar: the rounding of q and k perturbs every logit by about
     2^-11 (fp16) / 2^-8 (bf16) of |q||k|/sqrt(d), which moves the output by up to ~2e-3 (fp16) / ~1.5e-2 (bf16) of the
-    value scale -- recorded in INTEGRATION.md as a known difference from the reference's non-tensor-core decode."""
+    value scale (measured r3: 4.0e-4 fp16, 2.8e-3 bf16) -- recorded in INTEGRATION.md as a known difference from the reference's non-tensor-core decode."""
     hq, hkv, page_size = 8, 2, 16
     kv_lens = [54, 700, 1, 2049]
     torch.manual_seed(15)
@@ -172,7 +172,7 @@ def test_batch_decode_fused_rope_against_f32_rotation_oracle(dtype, d):
     err = (o.float().cpu() - o_ref.float()).abs().max().item()
     lerr = (lse.cpu() - lse_ref.float()).abs().max().item()
     print(f"decode fused RoPE vs f32-rotation oracle, {dtype} d={d}: max |o - ref| {err:.2e}, max |lse - ref| {lerr:.2e}")
-    bar = 4e-3 if dtype == torch.float16 else 3e-2
+    bar = 1e-3 if dtype == torch.float16 else 6e-3  # measured r3: 4.0e-4 / 2.8e-3
     assert err < bar and lerr < bar
 
 
