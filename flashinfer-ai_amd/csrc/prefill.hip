@@ -34,12 +34,17 @@ static bool use_fp8_native(const PrefillKernelParams& kp, int q_dt, int kv_dt, i
     const char* e = getenv("FI_PREFILL_FP8_NATIVE");
     return e ? atoi(e) != 0 : true;
   }();
+  static const bool d256 = [] {  // FI_PREFILL_FP8_NATIVE_D256=0: head_dim 256 through the upcast kernel (cross-check)
+    const char* e = getenv("FI_PREFILL_FP8_NATIVE_D256");
+    return e ? atoi(e) != 0 : true;
+  }();
   static const bool d64 = [] {
     const char* e = getenv("FI_PREFILL_FP8_NATIVE_D64");
     return e ? atoi(e) != 0 : true;
   }();
   return enabled && (q_dt == FI_DTYPE_FP8_E4M3 || q_dt == FI_DTYPE_FP8_E5M2) && kv_dt == q_dt &&
-         (head_dim == 128 || (head_dim == 64 && d64 && kp.tile_q == kTileQ)) &&
+         (head_dim == 128 || (head_dim == 64 && d64 && kp.tile_q == kTileQ) ||
+          (head_dim == 256 && d256 && kp.tile_q == kTileQ)) &&
          !rope && !kp.use_alibi && kp.logits_soft_cap == 0.f &&
          kp.window_left < 0 && !kp.custom_mask;
 }

@@ -9,7 +9,10 @@ template <int OUT16, bool BF8>
 static hipError_t launch_v2(const PrefillKernelParams& p, int head_dim, int grid, hipStream_t stream) {
   // group sizes 1 / 2 / 4: one query head per wave, logit scale in a scalar register (see the kernel)
   const bool uni = p.group_size == 1 || p.group_size == 2 || p.group_size == 4;
-  if (head_dim == 64) {
+  if (head_dim == 256) {  // one workgroup per CU, plain step (prefill_fp8_kernel.h)
+    if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8, 256><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+    else batch_prefill_fp8_kernel<OUT16, false, 4, BF8, 256><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
+  } else if (head_dim == 64) {
     if (uni) batch_prefill_fp8_kernel<OUT16, true, 4, BF8, 64><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
     else batch_prefill_fp8_kernel<OUT16, false, 4, BF8, 64><<<dim3(grid), dim3(kPrefillThreads), 0, stream>>>(p);
   } else if (p.tile_q == 2 * kTileQ) {  // plan cut for 256-row q tiles: the 8-wave form

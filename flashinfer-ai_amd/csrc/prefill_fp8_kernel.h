@@ -79,12 +79,17 @@ __device__ __forceinline__ f32x16 mfma_fp8_k64_fmt(i32x8 a, i32x8 b, f32x16 c) {
 }
 
 constexpr int kF8Stages = 4;        // ring depth (K and V each): tile t+1 / t read, t+2 landed, t+3 in flight
-constexpr int kF8KTile = kTileKV * 128;
-constexpr int kF8VOff = kF8Stages * kF8KTile;            // V ring after the K ring
-constexpr int kF8TabOff = 2 * kF8Stages * kF8KTile;      // uint64 [4][64] row byte offsets
 constexpr int kF8Ids = 1024;                             // page ids held in LDS
-constexpr int kF8IdsOff = kF8TabOff + 4 * kTileKV * 8;
-constexpr int kF8Smem = kF8IdsOff + kF8Ids * 4;          // 71 680 B: two workgroups per CU
+// LDS layout for head_dim D: [K ring: 4 stages][V ring: 4 stages][uint64 row-offset tables [4][64]][page ids];
+// a stage is 64 rows of max(D, 128) bytes (head_dim 64 keeps the 8 KB stride)
+template <int D>
+struct F8Lds {
+  static constexpr int kTile = kTileKV * (D > 128 ? D : 128);
+  static constexpr int kVOff = kF8Stages * kTile;
+  static constexpr int kTabOff = 2 * kF8Stages * kTile;
+  static constexpr int kIdsOff = kTabOff + 4 * kTileKV * 8;
+  static constexpr int kSmem = kIdsOff + kF8Ids * 4;  // 71 680 B at D <= 128 (two workgroups per CU), 137 216 B at 256
+};
 constexpr float kF8Thr = 3.0f;                           // log2 headroom of the deferred rescale
 constexpr float kF8Log2Scale = 8.807354922057604f - kF8Thr;   // log2(448) - headroom    (e4m3)
 constexpr float kBF8Log2Scale = 15.807354922057604f - kF8Thr;  // log2(57344) - headroom  (e5m2)
@@ -114,9 +119,15 @@ typedef const __attribute__((address_space(1))) void f8_gbl_void;
 // D: head_dim 128, or 64 (NW = 4 only): rows of 64 bytes in the same ring (a stage keeps its 8 KB stride), one k step
 // per QK^T block and two P.V blocks -- two MFMAs each per 64-key step against the same softmax work, so that form is
 // vector-bound by construction and its step is written plainly (builtin MFMAs, no hand interleave).
+// D = 256 (NW = 4; ref instantiation: hopper/quantization/prefill_sm90.cuh:459-470): 256-byte rows, 16 KB K / V tiles,
+// one workgroup per CU (128 accumulator + 32 query registers per lane: the 512-register budget of one wave per SIMD),
+// four k steps per QK^T block and eight P.V blocks per 64-key step -- 16 MFMAs against the same softmax, written plainly
+// like the head_dim 64 form.
 template <int OUT16, bool UNI, int NW, bool BF8, int D = 128>
-__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
-  static_assert(D == 128 || (D == 64 && NW == 4), "head_dim 128, or 64 with four waves");
+__global__ void __launch_bounds__(NW * 64, (NW == 8 || D == 256) ? 1 : 2) batch_prefill_fp8_kernel(const PrefillKernelParams p) {
+  static_assert(D == 128 || ((D == 64 || D == 256) && NW == 4), "head_dim 128, or 64 / 256 with four waves");
+  constexpr int kF8KTile = F8Lds<D>::kTile, kF8VOff = F8Lds<D>::kVOff, kF8TabOff = F8Lds<D>::kTabOff;
+  constexpr int kF8IdsOff = F8Lds<D>::kIdsOff, kF8Smem = F8Lds<D>::kSmem;
   constexpr int ROWB = D;             // bytes per K / V row in LDS
   constexpr int SLOTS = ROWB / 16;    // 16-byte slots per row
   constexpr int KBLK = 32 * ROWB;     // byte offset of the second 32-row block of a tile
@@ -191,7 +202,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (q, h) holds bytes [64 kk + 32 h, +32) of its row ----
   constexpr int KK = D / 64;  // k steps of QK^T
-  i32x8 qf[2];
+  i32x8 qf[KK < 2 ? 2 : KK];
   qf[1] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
   {
     const uint8_t* qrow = (const uint8_t*)p.q + (int64_t)(qo_start + qo_idx) * p.q_stride_n +
@@ -242,43 +253,51 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
   // swizzled by (row >> 2) & 3 -- the 16 rows one ds_read_b128 lane group touches then fill 256 bytes of banks -- and
   // V rows by bit 3 of the row on slot bit 1, which does the same for the 8 rows x 32 bytes of a transposed read)
   const int st_row = tid / SLOTS, st_slot = tid % SLOTS;
-  const int kc = (D == 128 ? (st_slot ^ ((st_row >> 1) & 7)) : (st_slot ^ ((st_row >> 2) & 3))) << 4;
-  const int vc = (D == 128 ? (st_slot ^ ((((st_row >> 1) & 1) << 1) | (((st_row >> 3) & 1) << 2)))
-                           : (st_slot ^ (((st_row >> 3) & 1) << 1))) << 4;
+  // (D = 256: a row is a whole 256-byte bank row, so the 16 rows of a ds_read_b128 lane group need all 16 chunk
+  // positions -- chunk ^ (row & 15) -- and the 8 rows x 32 bytes of a transposed read, rows {0..3, 8..11} (+ 4), take
+  // row bits 0, 1 and 3 onto chunk bits 1..3)
+  auto k_swz = [](int row) { return D == 256 ? (row & 15) : D == 128 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+  auto v_swz = [](int row) {
+    return D == 256 ? (((row & 3) | (((row >> 3) & 1) << 2)) << 1)
+         : D == 128 ? ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2))
+                    : (((row >> 3) & 1) << 1);
+  };
+  const int kc = (st_slot ^ k_swz(st_row)) << 4;
+  const int vc = (st_slot ^ v_swz(st_row)) << 4;
   const int64_t head_off = (int64_t)kv_head * p.kv_stride_h;
   const char* const k_thr = (const char*)p.k + head_off + kc;
   const char* const v_thr = (const char*)p.v + head_off + vc;
   const uint32_t stride_page32 = (uint32_t)p.kv_stride_page, stride_n32 = (uint32_t)p.kv_stride_n;
   // K fragment (A operand): row lq (+32 kb), chunks 4 kk + 2 lh + e, chunk ^ ((row >> 1) & 7)
-  int k_rd[2][2];
+  int k_rd[KK < 2 ? 2 : KK][2];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
+  for (int kk = 0; kk < (KK < 2 ? 2 : KK); ++kk)
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-      k_rd[kk][e] = D == 128 ? lq * 128 + (((4 * kk + 2 * lh + e) ^ ((lq >> 1) & 7)) << 4)
-                             : lq * 64 + (((2 * lh + e) ^ ((lq >> 2) & 3)) << 4);
+      k_rd[kk][e] = D == 64 ? lq * 64 + (((2 * lh + e) ^ k_swz(lq)) << 4)
+                            : lq * ROWB + (((4 * kk + 2 * lh + e) ^ k_swz(lq)) << 4);
   // V^T fragment.  P is the B operand in accumulator order (lane (q, h) holds the 32 probabilities kv = 32 kb + 8 g
   // + 4 h + e, kb < 2, g < 4, e < 4), so V must be the A operand with that k order along each head_dim row.  The V
   // tile stays ROW-MAJOR in LDS and is transposed on the way out by ds_read_b64_tr_b8: in a 16-lane group, lanes 2b
   // and 2b + 1 address the 16 bytes of "row b" (any row) and lane j receives byte j of rows 0..7 -- each lane
   // gathers, per read, the 8 kv rows of its k order for its own head_dim column: lane i of a group addresses row
   // b = i >> 1, bytes 8 (i & 1) .. +8 of chunk 2 db + g
-  int v_rd[4];  // [db]; head_dim 64 uses the first two
+  int v_rd[DBLK < 4 ? 4 : DBLK];  // [db]; head_dim 64 uses the first two
   {
     const int i16 = lane & 15, g = (lane >> 4) & 1, b = i16 >> 1;
     const int row = 4 * lh + (b & 3) + 8 * (b >> 2);
-    const int sw = D == 128 ? (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2) : ((row >> 3) & 1) << 1;
+    const int sw = v_swz(row);
     const int base = row * ROWB + ((g ^ sw) << 4) + 8 * (i16 & 1);
 #pragma unroll
-    for (int db = 0; db < 4; ++db) v_rd[db] = base ^ ((db & (DBLK - 1)) << 5);  // ring / stage / row-block offsets: immediates
+    for (int db = 0; db < (DBLK < 4 ? 4 : DBLK); ++db) v_rd[db] = base ^ ((db & (DBLK - 1)) << 5);  // ring / stage / row-block offsets: immediates
   }
   uint64_t* const tab = (uint64_t*)(smem + kF8TabOff);
   int32_t* const ids = (int32_t*)(smem + kF8IdsOff);
 
   // ---- running state ----
-  f32x16 o_acc[4];  // [db]; head_dim 64 uses the first two (the others are dead and cost nothing)
+  f32x16 o_acc[DBLK < 4 ? 4 : DBLK];  // [db]; head_dim 64 uses the first two (the others are dead and cost nothing)
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < (DBLK < 4 ? 4 : DBLK); ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o_acc[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
@@ -314,24 +333,30 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     // DMA of a tile's K and V rows into ring stage `stage`: the row offsets are read from table slot `slot` first
     // (dma_offsets, early in a step) and the four pieces are issued later (dma_issue), so that the LDS latency of
     // the table read does not sit at the top of the step
-    auto dma_offsets = [&](int slot, uint64_t& off0, uint64_t& off1) {
-      off0 = tab[slot * kTileKV + st_row];  // NW == 8: st_row covers all 64 rows, one K and one V piece per wave
-      off1 = (NW == 4 && D == 128) ? tab[slot * kTileKV + st_row + 32] : 0;
+    // a pass = the rows the workgroup's threads cover with one 16-byte chunk each (NW * 64 / SLOTS rows); the tile's
+    // 64 rows take PASSES of them (head_dim 256: four), one K and one V piece per wave and pass
+    constexpr int kRowsPerPass = kThreads / SLOTS;
+    constexpr int PASSES = kTileKV / kRowsPerPass;
+    static_assert(PASSES == 1 || PASSES == 2 || PASSES == 4, "passes per tile");
+    struct DmaOffs { uint64_t o[PASSES]; };
+    auto dma_offsets = [&](int slot, DmaOffs& f) {
+#pragma unroll
+      for (int j = 0; j < PASSES; ++j) f.o[j] = tab[slot * kTileKV + st_row + j * kRowsPerPass];
     };
-    auto dma_issue = [&](int stage, uint64_t off0, uint64_t off1) {
+    auto dma_issue = [&](int stage, const DmaOffs& f) {
       char* const kdst = smem + stage * kF8KTile + wave * 1024;
       char* const vdst = kdst + kF8VOff;
-      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off0), (f8_lds_void*)(kdst), 16, 0, 0);
-      if constexpr (NW == 4 && D == 128)
-        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + off1), (f8_lds_void*)(kdst + 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off0), (f8_lds_void*)(vdst), 16, 0, 0);
-      if constexpr (NW == 4 && D == 128)
-        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + off1), (f8_lds_void*)(vdst + 4096), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PASSES; ++j)
+        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(k_thr + f.o[j]), (f8_lds_void*)(kdst + j * NW * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PASSES; ++j)
+        __builtin_amdgcn_global_load_lds((f8_gbl_void*)(v_thr + f.o[j]), (f8_lds_void*)(vdst + j * NW * 1024), 16, 0, 0);
     };
     auto dma_tile = [&](int slot, int stage) {
-      uint64_t off0, off1;
-      dma_offsets(slot, off0, off1);
-      dma_issue(stage, off0, off1);
+      DmaOffs f;
+      dma_offsets(slot, f);
+      dma_issue(stage, f);
     };
 
     fill_ids();
@@ -343,12 +368,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
     dma_tile(2, 2);
     // tiles 0 and 1 have landed (tile 2: this wave's 4 (NW = 8: 2) pieces in flight); wait + barrier as one
     // statement (see the step)
-    constexpr bool kFourPieces = NW == 4 && D == 128;  // LDS-DMA pieces per wave and tile: 4, else 2
-    if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    // (LDS-DMA pieces per wave and tile: 2 * PASSES)
+    if constexpr (PASSES == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    else if constexpr (PASSES == 2) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
 
     // ---- building blocks ----
     const i32x8 q0 = qf[0], q1 = qf[1];
+    auto k_frag2 = [&](const char* kb, int kbk, int kk) {  // 32-key block kbk, k step kk of the K tile at kb
+      const u32x4 lo = *(const u32x4*)(kb + kbk * KBLK + k_rd[kk][0]);
+      const u32x4 hi = *(const u32x4*)(kb + kbk * KBLK + k_rd[kk][1]);
+      return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+    };
     auto k_frag = [&](const char* kb, int i) {  // fragment i = 2 kbk + kk of the K tile at kb
       const u32x4 lo = *(const u32x4*)(kb + (i >> 1) * KBLK + k_rd[i & 1][0]);
       const u32x4 hi = *(const u32x4*)(kb + (i >> 1) * KBLK + k_rd[i & 1][1]);
@@ -388,9 +419,15 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       // runtime index would push the accumulators into scratch memory for the whole kernel
       o_acc[0] = o_acc[0] * alpha;
       o_acc[1] = o_acc[1] * alpha;
-      if constexpr (D == 128) {
+      if constexpr (D >= 128) {
         o_acc[2] = o_acc[2] * alpha;
         o_acc[3] = o_acc[3] * alpha;
+      }
+      if constexpr (D == 256) {
+        o_acc[4] = o_acc[4] * alpha;
+        o_acc[5] = o_acc[5] * alpha;
+        o_acc[6] = o_acc[6] * alpha;
+        o_acc[7] = o_acc[7] * alpha;
       }
     };
     const float c_exp = UNI ? c_uni : c_lane;
@@ -436,8 +473,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
         s_a[0] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 1), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 0), q0, zero));
         s_a[1] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 3), q1, mfma_fp8_k64_fmt<BF8>(k_frag(smem, 2), q0, zero));
       } else {
-        s_a[0] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 0), q0, zero);
-        s_a[1] = mfma_fp8_k64_fmt<BF8>(k_frag(smem, 2), q0, zero);
+#pragma unroll
+        for (int kbk = 0; kbk < 2; ++kbk) {
+          s_a[kbk] = mfma_fp8_k64_fmt<BF8>(k_frag2(smem, kbk, 0), qf[0], zero);
+#pragma unroll
+          for (int kk = 1; kk < KK; ++kk) s_a[kbk] = mfma_fp8_k64_fmt<BF8>(k_frag2(smem, kbk, kk), qf[kk], s_a[kbk]);
+        }
       }
       if (tile_needs_mask(0)) apply_mask(0, s_a);
     }
@@ -452,33 +493,28 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       constexpr bool MASK = decltype(mask_c)::value;
       // table of tile t+4 -> the slot tile t's table used (read for the last time at step t-3)
       if (wave == ST) make_tab(t + 4, ST);
-      if constexpr (D == 64) {
-        // head_dim 64: the same step, plainly written -- two QK^T MFMAs (one k step), two P.V MFMAs
-        uint64_t off0, off1;
-        dma_offsets((ST + 3) & 3, off0, off1);
+      if constexpr (D != 128) {
+        // head_dim 64 / 256: the same step, plainly written (builtin MFMAs, the compiler's schedule between the
+        // fences) -- 2 KK QK^T MFMAs of tile t+1 with the four exp2 chunks of tile t between them, then DBLK P.V MFMAs
+        DmaOffs f;
+        dma_offsets((ST + 3) & 3, f);
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const char* const kb = smem + ((ST + 1) & 3) * kF8KTile;
         constexpr int VB = kF8VOff + ST * kF8KTile;
-        i32x2 va[4], vb[4];
-        va[0] = lds_tr8<VB + 0 * TRR>(v_rd[0]);
-        va[1] = lds_tr8<VB + 1 * TRR>(v_rd[0]);
-        va[2] = lds_tr8<VB + 2 * TRR>(v_rd[0]);
-        va[3] = lds_tr8<VB + 3 * TRR>(v_rd[0]);
-        vb[0] = lds_tr8<VB + 0 * TRR>(v_rd[1]);
-        vb[1] = lds_tr8<VB + 1 * TRR>(v_rd[1]);
-        vb[2] = lds_tr8<VB + 2 * TRR>(v_rd[1]);
-        vb[3] = lds_tr8<VB + 3 * TRR>(v_rd[1]);
-        const i32x8 kf0 = k_frag(kb, 0), kf1 = k_frag(kb, 2);
         int p8w[8];
         float cs0, cs1, cs2, cs3;
         __builtin_amdgcn_sched_barrier(0);
         exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
-        dma_issue((ST + 3) & 3, off0, off1);
+        dma_issue((ST + 3) & 3, f);
         __builtin_amdgcn_sched_barrier(0);
-        sn[0] = mfma_fp8_k64_fmt<BF8>(kf0, q0, zero);
+        sn[0] = mfma_fp8_k64_fmt<BF8>(k_frag2(kb, 0, 0), qf[0], zero);
+#pragma unroll
+        for (int kk = 1; kk < KK; ++kk) sn[0] = mfma_fp8_k64_fmt<BF8>(k_frag2(kb, 0, kk), qf[kk], sn[0]);
         exp_chunk(sc[0], 8, p8w[2], p8w[3], cs1);
         __builtin_amdgcn_sched_barrier(0);
-        sn[1] = mfma_fp8_k64_fmt<BF8>(kf1, q0, zero);
+        sn[1] = mfma_fp8_k64_fmt<BF8>(k_frag2(kb, 1, 0), qf[0], zero);
+#pragma unroll
+        for (int kk = 1; kk < KK; ++kk) sn[1] = mfma_fp8_k64_fmt<BF8>(k_frag2(kb, 1, kk), qf[kk], sn[1]);
         exp_chunk(sc[1], 0, p8w[4], p8w[5], cs2);
         exp_chunk(sc[1], 8, p8w[6], p8w[7], cs3);
         __builtin_amdgcn_sched_barrier(0);
@@ -491,19 +527,36 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
         }
         l_run += (cs0 + cs1) + (cs2 + cs3);
         const i32x8 p8 = {p8w[0], p8w[1], p8w[2], p8w[3], p8w[4], p8w[5], p8w[6], p8w[7]};
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
-        o_acc[0] = mfma_fp8_k64_fmt<BF8>(i32x8{va[0][0], va[0][1], va[1][0], va[1][1], va[2][0], va[2][1], va[3][0], va[3][1]},
-                                         p8, o_acc[0]);
-        o_acc[1] = mfma_fp8_k64_fmt<BF8>(i32x8{vb[0][0], vb[0][1], vb[1][0], vb[1][1], vb[2][0], vb[2][1], vb[3][0], vb[3][1]},
-                                         p8, o_acc[1]);
+        // V^T fragments two head_dim blocks at a time (the stage base goes into the address register: at head_dim 256
+        // the V ring starts beyond the 16-bit offset field of the LDS instructions)
+#pragma unroll
+        for (int db = 0; db < DBLK; db += 2) {
+          const int a0 = v_rd[db] + VB, a1 = v_rd[db + 1] + VB;
+          i32x2 va[4], vb[4];
+          va[0] = lds_tr8<0 * TRR>(a0);
+          va[1] = lds_tr8<1 * TRR>(a0);
+          va[2] = lds_tr8<2 * TRR>(a0);
+          va[3] = lds_tr8<3 * TRR>(a0);
+          vb[0] = lds_tr8<0 * TRR>(a1);
+          vb[1] = lds_tr8<1 * TRR>(a1);
+          vb[2] = lds_tr8<2 * TRR>(a1);
+          vb[3] = lds_tr8<3 * TRR>(a1);
+          asm volatile("s_waitcnt lgkmcnt(0)"
+                       : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+          __builtin_amdgcn_sched_barrier(0);  // an MFMA is no memory operation: keep it behind the wait (guide 5.4 rule 18)
+          o_acc[db] = mfma_fp8_k64_fmt<BF8>(
+              i32x8{va[0][0], va[0][1], va[1][0], va[1][1], va[2][0], va[2][1], va[3][0], va[3][1]}, p8, o_acc[db]);
+          o_acc[db + 1] = mfma_fp8_k64_fmt<BF8>(
+              i32x8{vb[0][0], vb[0][1], vb[1][0], vb[1][1], vb[2][0], vb[2][1], vb[3][0], vb[3][1]}, p8, o_acc[db + 1]);
+        }
         if constexpr (MASK) apply_mask(t + 1, sn);
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        return;
-      }
+        // in flight afterwards: V of tile t+2 and both operands of tile t+3 = 3 PASSES pieces of this wave
+        if constexpr (PASSES == 4) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
       // row offsets of tile t+3 (its DMA is issued inside region A, after the table read has returned)
-      uint64_t off0, off1;
-      dma_offsets((ST + 3) & 3, off0, off1);
+      DmaOffs f;
+      dma_offsets((ST + 3) & 3, f);
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const char* const kb = smem + ((ST + 1) & 3) * kF8KTile;  // tile t+1 (past the end: the last tile again)
       int p8w[8];
@@ -549,7 +602,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       __builtin_amdgcn_sched_barrier(0);  // every LDS read of the step's head is in flight before the first chunk
       exp_chunk(sc[0], 0, p8w[0], p8w[1], cs0);
       // new rows for the ring: tile t+3 into the stage tile t-1 left (every wave passed the barrier of t-1)
-      if (!(FI_PF8_KO & 2)) dma_issue((ST + 3) & 3, off0, off1);
+      if (!(FI_PF8_KO & 2)) dma_issue((ST + 3) & 3, f);
       __builtin_amdgcn_sched_barrier(0);
       FI_F8_QK0(sn[0], kf0, q0);
       kf0 = k_frag(kb, 2);
@@ -603,9 +656,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
       // which would hoist the next step's LDS reads between the wait and the barrier.
       // (in flight afterwards: V of tile t+2 and both operands of tile t+3 -- 6 pieces, 3 with NW = 8)
       if (!(FI_PF8_KO & 4)) {
-        if constexpr (kFourPieces) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (PASSES == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
+      }  // D == 128
     };
     auto refill_if_needed = [&](int t_first, int t_last) {
       if (p.kv_indices && !(ids_cover(t_first + 4) && ids_cover(t_last + 4))) {  // uniform; rare
@@ -676,7 +730,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) batch_prefill_fp8_ke
   // by the row), read back as whole rows -- 16 bytes per lane, 4 rows per store instruction.  Four packed
   // rows of one token are adjacent heads, i.e. adjacent 256-byte rows of the output tensor.
   {
-    char* const region = smem + wave * 8192;            // the K ring is idle now
+    char* const region = smem + wave * (D > 128 ? 64 * D : 8192);  // the K ring is idle now
     int64_t* const rowtab = (int64_t*)(smem + kF8TabOff) + wave * 32;
     if (lh == 0)
       rowtab[lq] = row_valid ? ((int64_t)(qo_start + qo_idx) * p.num_qo_heads + qo_head) * D : (int64_t)-1;

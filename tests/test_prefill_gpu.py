@@ -113,7 +113,7 @@ def test_batch_prefill_fp8_kv_cache(kv_dtype):
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("seq_len", [117, 509])
-@pytest.mark.parametrize("d", [128, 64])
+@pytest.mark.parametrize("d", [128, 64, 256])
 def test_single_prefill_fp8_qkv(causal, seq_len, d):
     """fp8 q/k/v with per-head scales.  Two bars: (1) against the oracle that restates the reference's
     fp8 arithmetic (P rounded to e4m3, 3-bit significand) -- rtol = atol = 5e-2: the e4m3 rounding of P is
@@ -237,7 +237,7 @@ def test_prefill_cuda_graph_mode_and_errors():
 
 
 @pytest.mark.parametrize("f8", [torch.float8_e4m3fn, torch.float8_e5m2])
-@pytest.mark.parametrize("d", [128, 64])
+@pytest.mark.parametrize("d", [128, 64, 256])
 def test_fp8_native_kernel_matches_upcast_kernel(f8, d):
     """The fp8-native kernel (MX-scaled MFMA, transposed V image) and the upcast-to-bf16 kernel implement
     the same arithmetic with the same 64-row tiles, so they must agree far tighter than the fp8 bar:
@@ -520,7 +520,7 @@ def _peaked_fp8_case(f8, d, kv_len, qo_len, tail_lo, tail_hi, peak, seed):
 
 
 @pytest.mark.parametrize("f8", [torch.float8_e4m3fn, torch.float8_e5m2])
-@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("d", [64, 128, 256])
 def test_fp8_prefill_peaked_rows(f8, d):
     """Long, peaked rows: one key at +12 nats, 8191 keys at -2..0 nats.  The tail terms are
     e^-12..e^-14 of the row maximum, i.e. at the bottom of the e4m3 range of P (the reference scales P by 448
