@@ -119,6 +119,27 @@ struct MfmaType<FI_DTYPE_BF16> {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 typedef __attribute__((address_space(3))) void lds_void;
 
+// 16-bit MFMA as an asm statement with chosen register classes (head_dim 256: the O accumulators -- 128 registers --
+// and the Q fragments -- 64 -- live in ACCUMULATOR registers, "a"; with the builtin the compiler kept shuttling ~400
+// values per tile between the two files because the rare rescale branch touches O with vector instructions).
+// CA: C / D in AGPRs, BA: the B operand in AGPRs.  The leading s_nop covers a vector write of an operand right in
+// front (hipcc pads nothing inside asm); readers of the result are fenced by hand at each use (mfma16_settle).
+template <int T16, bool CA, bool BA, typename Frag>
+__device__ __forceinline__ void mfma16_asm(f32x16& c, const Frag& a, const Frag& b) {
+#define FI_MFMA16_EMIT(NAME)                                                                                    \
+  if constexpr (CA && BA) asm volatile("s_nop 1\n\t" NAME " %0, %1, %2, %0" : "+a"(c) : "v"(a), "a"(b));        \
+  else if constexpr (CA) asm volatile("s_nop 1\n\t" NAME " %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));         \
+  else if constexpr (BA) asm volatile("s_nop 1\n\t" NAME " %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));         \
+  else asm volatile("s_nop 1\n\t" NAME " %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  if constexpr (T16 == FI_DTYPE_BF16) { FI_MFMA16_EMIT("v_mfma_f32_32x32x16_bf16") }
+  else { FI_MFMA16_EMIT("v_mfma_f32_32x32x16_f16") }
+#undef FI_MFMA16_EMIT
+}
+// result latency of the asm MFMAs (8 passes + 2 wait states) before anything but an accumulate-chain MFMA touches them
+#define FI_MFMA16_SETTLE_V2(x0, x1) asm volatile("s_nop 7\n\ts_nop 3" : "+v"(x0), "+v"(x1))
+#define FI_MFMA16_SETTLE_A8(o) \
+  asm volatile("s_nop 7\n\ts_nop 3" : "+a"(o[0]), "+a"(o[1]), "+a"(o[2]), "+a"(o[3]), "+a"(o[4]), "+a"(o[5]), "+a"(o[6]), "+a"(o[7]))
+
 // value held by the partner lane (lane ^ 32) via v_permlane32_swap (VALU; no LDS round trip)
 __device__ __forceinline__ float swap_halves(float x) {
   const uint32_t u = __builtin_bit_cast(uint32_t, x);
@@ -199,6 +220,11 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   constexpr bool P_HI_LO = PMODE == 1 && T16 == FI_DTYPE_BF16 && !Q_FP8;
   constexpr bool PV_F16 = PMODE == 2 && T16 == FI_DTYPE_BF16 && !Q_FP8;
   constexpr int TPV = PV_F16 ? FI_DTYPE_F16 : T16;  // operand type of the P.V MFMA
+#ifndef FI_PF_ACC_AGPR
+#define FI_PF_ACC_AGPR 1
+#endif
+  // head_dim 256 (one wave per SIMD, 512 registers = 256 vector + 256 accumulator): O and Q in accumulator registers
+  constexpr bool ACC_AGPR = FI_PF_ACC_AGPR && D == 256 && !Q_FP8;
   using MPV = MfmaType<TPV>;
   [[maybe_unused]] constexpr int KV_BYTES = KV_FP8 ? 1 : 2;
   constexpr int ROWB = D * 2;             // bytes per row of the 16-bit LDS images
@@ -649,15 +675,22 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
           if (i + PF < NK) kf[i + PF] = rd(i + PF);
-          s_acc[i / KSTEPS] = M::mfma(__builtin_bit_cast(frag_t, kf[i]), qf[i % KSTEPS], s_acc[i / KSTEPS]);
+          if constexpr (ACC_AGPR)
+            mfma16_asm<T16, false, true>(s_acc[i / KSTEPS], __builtin_bit_cast(frag_t, kf[i]), qf[i % KSTEPS]);
+          else
+            s_acc[i / KSTEPS] = M::mfma(__builtin_bit_cast(frag_t, kf[i]), qf[i % KSTEPS], s_acc[i / KSTEPS]);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+        if constexpr (!ACC_AGPR) {  // (asm MFMAs keep their source order by themselves)
+          __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
-        for (int i = 0; i < NK - PF; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          for (int i = 0; i < NK - PF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
+        } else {
+          FI_MFMA16_SETTLE_V2(s_acc[0], s_acc[1]);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
       }
       // nothing of the staging below (it waits for the K loads issued at the top) may move up into QK^T
       __builtin_amdgcn_sched_barrier(0);
@@ -749,6 +782,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
         const float alpha = fast_exp2(m_run - m_true);
         m_run = m_true;
         l_run *= alpha;
+        if constexpr (ACC_AGPR) FI_MFMA16_SETTLE_A8(o_acc);
 #pragma unroll
         for (int db = 0; db < DBLK; ++db)
 #pragma unroll
@@ -812,9 +846,15 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
                 (__attribute__((address_space(3))) s16x4*)(base + 8 * ROWB));
             using s16x8 = __attribute__((ext_vector_type(8))) short;
             const s16x8 a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o_acc[db] = MPV::mfma(__builtin_bit_cast(pv_frag_t, a8), pfrag, o_acc[db]);
-            if constexpr (P_HI_LO)
-              o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, w_lo), o_acc[db]);
+            if constexpr (ACC_AGPR) {
+              mfma16_asm<TPV, true, false>(o_acc[db], __builtin_bit_cast(pv_frag_t, a8), pfrag);
+              if constexpr (P_HI_LO)
+                mfma16_asm<T16, true, false>(o_acc[db], __builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, w_lo));
+            } else {
+              o_acc[db] = MPV::mfma(__builtin_bit_cast(pv_frag_t, a8), pfrag, o_acc[db]);
+              if constexpr (P_HI_LO)
+                o_acc[db] = M::mfma(__builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, w_lo), o_acc[db]);
+            }
           }
         }
       }
@@ -829,6 +869,7 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       tile_body(std::integral_constant<int, 1>{}, t + 1);
     }
     if (t < num_tiles) tile_body(std::integral_constant<int, 0>{}, t);
+    if constexpr (ACC_AGPR) FI_MFMA16_SETTLE_A8(o_acc);
   }
 
   // ---- finalize (ref: prefill.cuh:2378-2403; fp8: attention_updater.cuh:221-240) ----
