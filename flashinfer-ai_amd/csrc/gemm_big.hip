@@ -31,8 +31,8 @@ constexpr int kBigTM = 256, kBigTN = 256;
 constexpr int kBigScOff = (kBigTM + kBigTN) * kBK;              // 64 KB of operands, then the scales
 constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64 A scales, 64 x the B scale
 
-#ifndef FI_GEMM_BIG_SPREAD
-#define FI_GEMM_BIG_SPREAD 0
+#ifndef FI_GEMM_BIG_BRANCHFREE
+#define FI_GEMM_BIG_BRANCHFREE 3  // bit 0: hardware-scale path, bit 1: fold path (see k_step)
 #endif
 #ifndef FI_GEMM_BIG_BAND
 #define FI_GEMM_BIG_BAND 1024
@@ -243,10 +243,12 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
       const int mi = p.a_gran_m == 1 ? m : m / p.a_gran_m;
       a_sc_voff = (uint32_t)(p.scale_k_major ? mi * kblocks : mi) * 4u;
     }
-    auto dma_pieces = [&](int kb, int stage, auto first_c, auto count_c) {
+    // oob = 0x80000000 pushes every lane's offset past the descriptor's range: the pieces are then written as zeros
+    // without a memory access (see k_step)
+    auto dma_pieces = [&](int kb, int stage, auto first_c, auto count_c, uint32_t oob = 0) {
       constexpr int first = decltype(first_c)::value, count = decltype(count_c)::value;
       const int koff = kb * kBK;
-      uint32_t vb = v_par0;
+      uint32_t vb = v_par0 + oob;
       asm volatile("" : "+v"(vb));  // the piece offsets are recomputed here, not kept across the k loop
 #pragma unroll
       for (int j2 = first; j2 < first + count; ++j2) {
@@ -256,17 +258,17 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
             koff, 0, 0);
       }
     };
-    auto dma_scales = [&](int kb, int stage) {
+    auto dma_scales = [&](int kb, int stage, uint32_t oob = 0) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           a_sc_rsrc, (__attribute__((address_space(3))) void*)(&smem[stage * kBigStage + kBigScOff + wave * 512]), 4,
-          a_sc_voff, kb * a_sc_stride * 4, 0, 0);
+          a_sc_voff + oob, kb * a_sc_stride * 4, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           b_sc_rsrc, (__attribute__((address_space(3))) void*)(&smem[stage * kBigStage + kBigScOff + wave * 512 + 256]),
-          4, 0, kb * b_sc_stride * 4, 0, 0);
+          4, oob, kb * b_sc_stride * 4, 0, 0);
     };
-    auto dma = [&](int kb, int stage) {
-      dma_pieces(kb, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
-      dma_scales(kb, stage);
+    auto dma = [&](int kb, int stage, uint32_t oob = 0) {
+      dma_pieces(kb, stage, std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, oob);
+      dma_scales(kb, stage, oob);
     };
     // block 0 of the next tile goes out BEFORE the finished tile is converted and stored (stage 0; the store's
     // scratch is stage 1, which block 1 enters only in step 0, behind the barrier below)
@@ -292,10 +294,15 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
 
     auto k_step = [&](auto par_c, const int kb) {
       constexpr int buf = decltype(par_c)::value;  // == kb % 2
-      const bool more = kb + 1 < kblocks && (!(FI_GEMM_BIG_KO & 4) || kb == 0);
-      if (more) {  // into the stage read in step kb - 1
-        if (FI_GEMM_BIG_SPREAD) dma_scales(kb + 1, buf ^ 1);
-        else dma(kb + 1, buf ^ 1);
+      // Block kb + 1 goes into the stage read in step kb - 1.  No branch on "is there a block kb + 1": a branch
+      // here splits the step's scheduling region (the allocator then spills around it, and the last step's copy
+      // of the loop body cost 7 % of C4).  The LAST step issues the same instructions with every lane's offset
+      // pushed out of the descriptor's range: zeros, written without a memory access into the stage nobody reads.
+      if (FI_GEMM_BIG_BRANCHFREE & (HWS ? 1 : 2)) {
+        const uint32_t oob = kb + 1 < kblocks ? 0u : 0x80000000u;
+        if (!(FI_GEMM_BIG_KO & 4) || kb == 0) dma(min(kb + 1, kblocks - 1), buf ^ 1, oob);
+      } else if (kb + 1 < kblocks && (!(FI_GEMM_BIG_KO & 4) || kb == 0)) {
+        dma(kb + 1, buf ^ 1);
       }
       asm volatile("" : "+v"(a_rd_base), "+v"(b_rd_base));
       const uint8_t* const stage = &smem[buf * kBigStage];
@@ -355,12 +362,6 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
             fb[cur ^ 1][0] = frag(b_rd_base, 0, nb + 1);
             fb[cur ^ 1][1] = frag(b_rd_base, 1, nb + 1);
           }
-          if (FI_GEMM_BIG_SPREAD && more) {
-            if (nb == 0) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-            if (nb == 1) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-            if (nb == 2) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
-            if (nb == 3) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
-          }
           acc[nb][1] = mfma_s(fb[cur][0], fa[1][0], acc[nb][1], e_a1);
           acc[nb][0] = mfma_s(fb[cur][1], fa[0][1], acc[nb][0], e_a0);
           acc[nb][1] = mfma_s(fb[cur][1], fa[1][1], acc[nb][1], e_a1);
@@ -386,14 +387,6 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
           fb[cur ^ 1][1] = frag(b_rd_base, 1, nb + 1);
         }
         if (nb > 0) fold(nb - 1, 1, p1, s1);
-        // FI_GEMM_BIG_SPREAD: the 8 operand pieces of block kb + 1 go out two per n block, in the shadow of
-        // the MFMAs, instead of all at the top of the step
-        if (FI_GEMM_BIG_SPREAD && more) {
-          if (nb == 0) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-          if (nb == 1) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-          if (nb == 2) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
-          if (nb == 3) dma_pieces(kb + 1, buf ^ 1, std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{});
-        }
         __builtin_amdgcn_sched_barrier(0);
         p0 = mfma1(fb[cur][1], fa[0][1], p0);
         p1 = mfma0(fb[cur][0], fa[1][0]);
