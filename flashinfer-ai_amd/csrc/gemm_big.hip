@@ -31,6 +31,9 @@ constexpr int kBigTM = 256, kBigTN = 256;
 constexpr int kBigScOff = (kBigTM + kBigTN) * kBK;              // 64 KB of operands, then the scales
 constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64 A scales, 64 x the B scale
 
+#ifndef FI_GEMM_BIG_NT_STORE
+#define FI_GEMM_BIG_NT_STORE 1  // output stores non-temporal: 128 KB per tile that nobody reads again stay out of the L2's way
+#endif
 #ifndef FI_GEMM_BIG_BRANCHFREE
 #define FI_GEMM_BIG_BRANCHFREE 3  // bit 0: hardware-scale path, bit 1: fold path (see k_step)
 #endif
@@ -168,7 +171,8 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
         if (m >= out_m_end || n >= N) continue;  // n is a multiple of 8 and so is N
         uint16_t* dst = (uint16_t*)p.d + (int64_t)m * N + n;
         if (d_aligned16) {
-          *(u32x4*)dst = v;
+          if (FI_GEMM_BIG_NT_STORE) __builtin_nontemporal_store(v, (u32x4*)dst);
+          else *(u32x4*)dst = v;
         } else {
           *(u32x2*)dst = u32x2{v[0], v[1]};
           *(u32x2*)(dst + 4) = u32x2{v[2], v[3]};

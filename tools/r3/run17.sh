@@ -4,8 +4,8 @@ timeout -k 10 600 python -m pytest tests/test_gemm_gpu.py -x -q -m gpu 2>&1 | ta
 for rep in 1 2; do
 for v in new old; do
   if [ $v = new ]; then unset FI_MI355_LIB; else export FI_MI355_LIB=$GRAFT_REPO_ROOT/flashinfer-ai_amd/flashinfer/ko/libfi_gemm_big_0.so; fi
-  echo "variant=$v (new = no branch on 'is there a next k block')"
+  echo "variant=$v (new = non-temporal output stores)"
   timeout -k 10 300 python tools/bench_c4.py 2>&1 | grep -v amdgpu.ids || exit 1
 done
 done
-timeout -k 10 300 python tools/bench_gemm.py 2>&1 | grep -v amdgpu.ids | tail -12
+unset FI_MI355_LIB; timeout -k 10 300 python tools/bench_gemm.py 2>&1 | grep -v amdgpu.ids | tail -12
