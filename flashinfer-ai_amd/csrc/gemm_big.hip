@@ -34,6 +34,9 @@ constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64
 #ifndef FI_GEMM_BIG_NT_STORE
 #define FI_GEMM_BIG_NT_STORE 1  // output stores non-temporal: 128 KB per tile that nobody reads again stay out of the L2's way
 #endif
+#ifndef FI_GEMM_BIG_CARRY
+#define FI_GEMM_BIG_CARRY 2  // 0 none, 1 the held-back pair behind the DMA issue, 2 in front of it
+#endif
 #ifndef FI_GEMM_BIG_BRANCHFREE
 #define FI_GEMM_BIG_BRANCHFREE 3  // bit 0: hardware-scale path, bit 1: fold path (see k_step)
 #endif
@@ -44,7 +47,7 @@ constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64
 #define FI_GEMM_BIG_INTERLEAVE 1
 #endif
 #ifndef FI_GEMM_BIG_KO
-#define FI_GEMM_BIG_KO 0  // experiments only, bit mask: 1 no output stores, 2 no fold, 4 no DMA in the k loop
+#define FI_GEMM_BIG_KO 0  // experiments only, bit mask: 1 no output stores, 2 no fold, 4 no DMA in the k loop, 8 / 32 (timing only, wrong results): the step awaits none / all but the newest block of its DMA
 #endif
 
 // 1 in *flag when some scale is not a positive normal power of two (flag zeroed by the launcher).  HBM-bound, a few
@@ -291,6 +294,18 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
     // block 0 landed (the output stores are younger and vmcnt retires in order: 0 is the only safe count);
     // every wave is done with its stage 1 scratch
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // Hardware-scale path (FI_GEMM_BIG_CARRY): the last two MFMAs of a step (n block 3, second k half) are held
+    // back and issued BEHIND the barrier, in front of the next step's first MFMA -- the matrix pipe has work while
+    // the new step's DMA instructions issue and its first fragment reads are in flight.  Their operands (the A
+    // fragments' second k halves, one B fragment, the step's scale exponents) stay in the registers they are in;
+    // the new step's reads go to the first-k-half registers first.  Zero operands in front of step 0.
+    i32x8g hfa[2][2];  // [m block][k half]
+    i32x8g hfb[2][2];  // [n block parity][k half]
+    int he_b = 127, he_a0 = 127, he_a1 = 127;
+    if constexpr (HWS && FI_GEMM_BIG_CARRY) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) hfa[0][1][r] = hfa[1][1][r] = hfb[1][1][r] = 0;
+    }
     f32x16g p_carry;  // block (3, 1) of the previous k step, folded at the start of the next one
 #pragma unroll
     for (int r = 0; r < 16; ++r) p_carry[r] = 0.f;
@@ -302,9 +317,13 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
       // here splits the step's scheduling region (the allocator then spills around it, and the last step's copy
       // of the loop body cost 7 % of C4).  The LAST step issues the same instructions with every lane's offset
       // pushed out of the descriptor's range: zeros, written without a memory access into the stage nobody reads.
-      if (FI_GEMM_BIG_BRANCHFREE & (HWS ? 1 : 2)) {
+      auto dma_next = [&]() {
         const uint32_t oob = kb + 1 < kblocks ? 0u : 0x80000000u;
         if (!(FI_GEMM_BIG_KO & 4) || kb == 0) dma(min(kb + 1, kblocks - 1), buf ^ 1, oob);
+      };
+      constexpr bool kDmaBehindCarry = HWS && FI_GEMM_BIG_CARRY == 2;
+      if (FI_GEMM_BIG_BRANCHFREE & (HWS ? 1 : 2)) {
+        if (!kDmaBehindCarry) dma_next();
       } else if (kb + 1 < kblocks && (!(FI_GEMM_BIG_KO & 4) || kb == 0)) {
         dma(kb + 1, buf ^ 1);
       }
@@ -349,6 +368,50 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
       const float* const sc = (const float*)(&smem[buf * kBigStage + kBigScOff + wave * 512]);
       const float sa[2] = {sc[lq], sc[32 + lq]};
       const float sb = sc[64 + lane];
+      if constexpr (HWS && FI_GEMM_BIG_CARRY) {
+        const float* const sc = (const float*)(&smem[buf * kBigStage + kBigScOff + wave * 512]);
+        const float sa0 = sc[lq], sa1 = sc[32 + lq], sb = sc[64 + lane];
+        hfa[0][0] = frag(a_rd_base, 0, 0);
+        hfb[0][0] = frag(b_rd_base, 0, 0);
+        hfa[1][0] = frag(a_rd_base, 0, 1);
+        auto mfma_c = [&](const i32x8g& b, const i32x8g& a, const f32x16g& c, int eb, int ea) {
+          return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, MA_E5M2 ? 1 : 0, MB_E5M2 ? 1 : 0, 0, eb, 0, ea);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        // the previous step's held-back pair
+        acc[3][0] = mfma_c(hfb[1][1], hfa[0][1], acc[3][0], he_b, he_a0);
+        acc[3][1] = mfma_c(hfb[1][1], hfa[1][1], acc[3][1], he_b, he_a1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kDmaBehindCarry) {
+          dma_next();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        hfa[0][1] = frag(a_rd_base, 1, 0);
+        hfb[0][1] = frag(b_rd_base, 1, 0);
+        hfa[1][1] = frag(a_rd_base, 1, 1);
+        he_b = (int)(__builtin_bit_cast(uint32_t, sb) >> 23);
+        he_a0 = (int)(__builtin_bit_cast(uint32_t, sa0) >> 23);
+        he_a1 = (int)(__builtin_bit_cast(uint32_t, sa1) >> 23);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int cur = nb & 1;
+          acc[nb][0] = mfma_c(hfb[cur][0], hfa[0][0], acc[nb][0], he_b, he_a0);
+          if (nb < 3) {
+            hfb[cur ^ 1][0] = frag(b_rd_base, 0, nb + 1);
+            hfb[cur ^ 1][1] = frag(b_rd_base, 1, nb + 1);
+          }
+          acc[nb][1] = mfma_c(hfb[cur][0], hfa[1][0], acc[nb][1], he_b, he_a1);
+          if (nb < 3) {
+            acc[nb][0] = mfma_c(hfb[cur][1], hfa[0][1], acc[nb][0], he_b, he_a0);
+            acc[nb][1] = mfma_c(hfb[cur][1], hfa[1][1], acc[nb][1], he_b, he_a1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+      }
       if constexpr (HWS) {
         // E8M0 = the f32 exponent field of a power of two.  MFMA A operand = B matrix rows (one scale per wave: sb),
         // MFMA B operand = A matrix rows, the lane's row (sa)
@@ -371,7 +434,9 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
           acc[nb][1] = mfma_s(fb[cur][1], fa[1][1], acc[nb][1], e_a1);
           __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (FI_GEMM_BIG_KO & 8) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (FI_GEMM_BIG_KO & 32) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         return;
       }
@@ -416,6 +481,11 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
     if constexpr (!HWS) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[3][1][r] += s_carry * p_carry[r];
+    } else if constexpr (FI_GEMM_BIG_CARRY) {
+      acc[3][0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hfb[1][1], hfa[0][1], acc[3][0], MA_E5M2 ? 1 : 0,
+                                                                  MB_E5M2 ? 1 : 0, 0, he_b, 0, he_a0);
+      acc[3][1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(hfb[1][1], hfa[1][1], acc[3][1], MA_E5M2 ? 1 : 0,
+                                                                  MB_E5M2 ? 1 : 0, 0, he_b, 0, he_a1);
     }
   }
   if (have_out && (!(FI_GEMM_BIG_KO & 1) || p.k == 12345)) store_tile();
