@@ -72,6 +72,23 @@ RATES = [
     ("v_exp_f32", "v_exp_f32 {d}, {d}"),
     ("v_cvt_pk_fp8_f32", "v_cvt_pk_fp8_f32 {d}, {a}, {b}"),
     ("v_cvt_pk_fp8_f32 op_sel hi", "v_cvt_pk_fp8_f32 {d}, {a}, {b} op_sel:[0,0,1]"),
+    ("v_cvt_pk_u8_f32 d,a,1,d", "v_cvt_pk_u8_f32 {d}, {a}, 1, {d}"),
+    ("v_cvt_pk_u8_f32 d,a,b,d (vgpr byte select)", "v_cvt_pk_u8_f32 {d}, {a}, {b}, {d}"),
+    ("v_cvt_u32_f32", "v_cvt_u32_f32 {d}, {a}"),
+    ("v_cvt_i32_f32", "v_cvt_i32_f32 {d}, {a}"),
+    ("v_cvt_f32_i32", "v_cvt_f32_i32 {d}, {a}"),
+    ("v_cvt_pk_f16_f32 (pkrtz)", "v_cvt_pkrtz_f16_f32 {d}, {a}, {b}"),
+    ("v_cvt_pk_bf16_f32", "v_cvt_pk_bf16_f32 {d}, {a}, {b}"),
+    ("v_perm_b32", "v_perm_b32 {d}, {a}, {b}, %12"),
+    ("v_ldexp_f32", "v_ldexp_f32 {d}, {a}, {b}"),
+    ("v_med3_f32", "v_med3_f32 {d}, {d}, {a}, {b}"),
+    ("v_max_f32 d,d,d", "v_max_f32 {d}, {d}, {d}"),
+    ("v_cvt_scalef32_pk_fp8_f32", "v_cvt_scalef32_pk_fp8_f32 {d}, {a}, {b}, %12"),
+    ("v_lshl_or_b32", "v_lshl_or_b32 {d}, {a}, 8, {d}"),
+    ("v_add3_u32", "v_add3_u32 {d}, {d}, {a}, {b}"),
+    ("v_floor_f32", "v_floor_f32 {d}, {a}"),
+    ("v_fract_f32", "v_fract_f32 {d}, {a}"),
+    ("v_rndne_f32", "v_rndne_f32 {d}, {a}"),
     ("s_nop 0", "s_nop 0"),
     ("s_mov_b32 (SALU)", "s_mov_b32 s21, s20"),
     ("v_readfirstlane", "v_readfirstlane_b32 s21, {a}"),
