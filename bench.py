@@ -489,11 +489,11 @@ def main():
         # HBM bytes per launch from the PMC passes (2 * FETCH_SIZE + WRITE_SIZE, gfx950 rule): NOT measured by
         # this run -- a cached rocprofv3 result of the same config, labelled as such; dropped when the config differs
         traffic, traffic_source = None, None
-        pmc = os.path.join(ROOT, "profiles", "r02_c2_decode_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r03_c2_decode_traffic.json")
         if os.path.exists(pmc) and not args.no_permute:
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/r02_c2_decode_traffic.json (rocprofv3 --pmc of this config and kernel, tools/prof_c2.sh; not this run)"
+                traffic_source = "profiles/r03_c2_decode_traffic.json (rocprofv3 --pmc of this config and kernel, tools/prof_r03.sh; not this run)"
             except Exception:
                 traffic = None
         line = {
