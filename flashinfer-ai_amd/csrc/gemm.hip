@@ -636,14 +636,18 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     }
     return hipGetLastError();
   }
-  // 256 x 256 tiles (gemm_big.hip) once every CU gets a few of them; FI_GEMM_BIG=0 keeps 256 x 128
+  // 256 x 256 tiles (gemm_big.hip) from half a tile per CU on; FI_GEMM_BIG=0 keeps 256 x 128 / 128 x 128.
+  // r3 (tools/bench_gemm_threshold.py, reference-quantised inputs): since the hardware-scale path and the branch-free
+  // k step the 256 x 256 kernel beats the 256 x 128 LDS-DMA kernel on every shape that reaches either (8 x 1024 x
+  // 4096 x 7168: 2.32 against 1.37 PFLOP/s; 256 tiles = one per CU: 1.27 against 1.10) and the 128 x 128 kernel from
+  // 128 tiles on (2048 x 4096 x 4096: 1.12 against 0.83); at 64 tiles the 128 x 128 kernel's 256 workgroups win.
   static const int big_min_tiles = [] {
     const char* e = getenv("FI_GEMM_BIG");
     if (e && atoi(e) == 0) return -1;
     const char* t = getenv("FI_GEMM_BIG_MIN_TILES");
-    return t ? atoi(t) : 4 * fi_num_compute_units();
+    return t ? atoi(t) : fi_num_compute_units() / 2;
   }();
-  if (use_ws && use_dma && big_min_tiles >= 0 && !tall &&
+  if (use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && use_dma && big_min_tiles >= 0 && !tall &&
       p.num_m_tiles_bound_ws * ceil_div(p.n, 2 * kBN) >= big_min_tiles) {
     GemmParams q = p;
     q.num_m_tiles_bound = p.num_m_tiles_bound_ws;

@@ -1,6 +1,7 @@
 """GPU: every GEMM shape of tests/test_gemm_gpu.py through each large-problem kernel.
 
-The library picks the kernel by problem size (256 x 128 persistent kernels from 2 x CUs tiles on) and reads its
+The library picks the kernel by problem size (256 x 256 tiles from half a tile per CU on, 128 x 256 tiles for groups
+of few rows, the 128 x 128 kernel below that) and reads its
 switches once per process, so the forced variants run in a child process:
   FI_GEMM_WS_MIN_TILES=0 FI_GEMM_BIG_MIN_TILES=0 -> every shape takes the 256 x 256 kernel (gemm_big.hip)
   FI_GEMM_WS_MIN_TILES=0 FI_GEMM_DMA_TM=256 / 128 -> every shape takes the persistent LDS-DMA kernel with
