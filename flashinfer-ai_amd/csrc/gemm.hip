@@ -36,6 +36,8 @@ __device__ __forceinline__ f32x16g mfma_fp8(long a, long b, f32x16g c) {
 // product at twice the rate of the non-scaled fp8 MFMA (MI355X_MICROARCH.md, matrix cores).
 template <bool MA_E5M2, bool MB_E5M2, bool MX>
 __global__ void __launch_bounds__(kGemmThreads, 2) group_gemm_fp8_kernel(const GemmParams p) {
+  // the 256 x 256 kernel's hardware-scale variant already did this call (launch_gemm: mid-size problems)
+  if (fi_scales_are_pow2(p.pow2_flag)) return;
   __shared__ __attribute__((aligned(16))) uint8_t smem[2][2][kBM * kBK];  // [stage][A|B]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -300,6 +302,7 @@ constexpr int kWsBM = 256;
 // -- `__syncthreads()` would drain vmcnt.
 template <bool MA_E5M2, bool MB_E5M2, int TM>
 __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const GemmParams p) {
+  if (fi_scales_are_pow2(p.pow2_flag)) return;  // see group_gemm_fp8_kernel
   // TM x TN output tile, TM + TN = 384 rows of operands per k block: 256 x 128, or 128 x 256 for groups of few
   // rows (a group of <= 128 rows wastes half of a 256-row tile, and B -- streamed once from HBM when every group
   // has a single m tile -- gets twice the bytes in flight)
@@ -600,7 +603,8 @@ __global__ void __launch_bounds__(kWsThreads, 1) group_gemm_fp8_dma_kernel(const
   if (have_out) store_tile();
 }
 
-static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
+static hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
   const int grid = p.num_m_tiles_bound * p.n_tiles;
   if (grid <= 0) return hipSuccess;
   // MFMA A operand = GEMM matrix B, MFMA B operand = GEMM matrix A
@@ -636,22 +640,38 @@ static hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     }
     return hipGetLastError();
   }
-  // 256 x 256 tiles (gemm_big.hip) from half a tile per CU on; FI_GEMM_BIG=0 keeps 256 x 128 / 128 x 128.
-  // r3 (tools/bench_gemm_threshold.py, reference-quantised inputs): since the hardware-scale path and the branch-free
-  // k step the 256 x 256 kernel beats the 256 x 128 LDS-DMA kernel on every shape that reaches either (8 x 1024 x
-  // 4096 x 7168: 2.32 against 1.37 PFLOP/s; 256 tiles = one per CU: 1.27 against 1.10) and the 128 x 128 kernel from
-  // 128 tiles on (2048 x 4096 x 4096: 1.12 against 0.83); at 64 tiles the 128 x 128 kernel's 256 workgroups win.
-  static const int big_min_tiles = [] {
+  // 256 x 256 tiles (gemm_big.hip); FI_GEMM_BIG=0 keeps 256 x 128 / 128 x 128.  r3 (tools/bench_gemm_threshold.py):
+  //  * power-of-two scales (the reference quantiser's; decided on the device): the hardware-scale variant beats the
+  //    256 x 128 LDS-DMA kernel on every shape that reaches either (8 x 1024 x 4096 x 7168: 2.32 against 1.37 PFLOP/s;
+  //    256 tiles = one per CU: 1.27 against 1.10) and the 128 x 128 kernel from 128 tiles on (2048 x 4096 x 4096: 1.12
+  //    against 0.83) -> from one tile per CU on (below that the ~15 us of the check kernel and of the variant that
+  //    returns at once are a tenth of the call for the scales that do NOT qualify);
+  //  * arbitrary scales (the fold variant): mixed below four tiles per CU (8 x 1024 x 4096 x 7168 1.57 against 1.32,
+  //    4 x 1024 x 7168 x 2048 0.88 against 1.18) -> from 4 x CUs tiles on, as in r2.
+  // In between only the hardware-scale variant is launched (it returns at once when the scales do not qualify) and
+  // the kernel chosen below gets the flag word and returns at once when they do.
+  static const int big_hws_min_tiles = [] {
     const char* e = getenv("FI_GEMM_BIG");
     if (e && atoi(e) == 0) return -1;
     const char* t = getenv("FI_GEMM_BIG_MIN_TILES");
-    return t ? atoi(t) : fi_num_compute_units() / 2;
+    return t ? atoi(t) : fi_num_compute_units();
   }();
-  if (use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && use_dma && big_min_tiles >= 0 && !tall &&
-      p.num_m_tiles_bound_ws * ceil_div(p.n, 2 * kBN) >= big_min_tiles) {
+  static const int big_fold_min_tiles = [] {
+    const char* t = getenv("FI_GEMM_BIG_FOLD_MIN_TILES");
+    if (t) return atoi(t);
+    const char* h = getenv("FI_GEMM_BIG_MIN_TILES");  // a forced threshold (tests, A/B runs) applies to both variants
+    return h ? atoi(h) : 4 * fi_num_compute_units();
+  }();
+  const int big_tiles = p.num_m_tiles_bound_ws * ceil_div(p.n, 2 * kBN);
+  const bool big_ok = use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && use_dma && big_hws_min_tiles >= 0 && !tall;
+  if (big_ok && big_tiles >= big_hws_min_tiles) {
     GemmParams q = p;
     q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
-    return launch_gemm_big(q, ws_grid, stream);
+    if (big_tiles >= big_fold_min_tiles) return launch_gemm_big(q, ws_grid, stream, nullptr);
+    uint32_t* flag = nullptr;
+    hipError_t e = launch_gemm_big(q, ws_grid, stream, &flag);
+    if (e != hipSuccess) return e;
+    p.pow2_flag = flag;  // null (no flag ring yet under a stream capture, FI_GEMM_HW_SCALES=0): nothing was launched
   }
   if (use_ws && use_dma) {
     GemmParams q = p;

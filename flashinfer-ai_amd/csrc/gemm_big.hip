@@ -50,10 +50,13 @@ constexpr int kBigStage = kBigScOff + (kBigThreads / 64) * 512;  // per wave: 64
 #define FI_GEMM_BIG_KO 0  // experiments only, bit mask: 1 no output stores, 2 no fold, 4 no DMA in the k loop, 8 / 32 (timing only, wrong results): the step awaits none / all but the newest block of its DMA
 #endif
 
-// 1 in *flag when some scale is not a positive normal power of two (flag zeroed by the launcher).  HBM-bound, a few
-// microseconds: C4's a_scale is 4 MB.
+// flag[block] = 1 when the block saw a scale that is not a positive normal power of two, else 0 (kPow2Words blocks:
+// every word of the call's slot is rewritten, nothing to reset).  HBM-bound, a few microseconds: C4's a_scale is 4 MB.
 __global__ void __launch_bounds__(256) scales_pow2_check_kernel(const uint32_t* a_scale, int64_t na, const uint32_t* b_scale,
                                                                   int64_t nb, uint32_t* flag) {
+  __shared__ uint32_t any_bad;
+  if (threadIdx.x == 0) any_bad = 0;
+  __syncthreads();
   bool bad = false;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
@@ -61,7 +64,9 @@ __global__ void __launch_bounds__(256) scales_pow2_check_kernel(const uint32_t* 
     const uint32_t e = w >> 23;  // sign | exponent
     bad |= (w & 0x007fffffu) != 0 || e == 0 || e >= 255;
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+  if (__any(bad) && (threadIdx.x & 63) == 0) any_bad = 1;  // benign race: every writer stores 1
+  __syncthreads();
+  if (threadIdx.x == 0) flag[blockIdx.x] = any_bad;
 }
 
 // HWS: the scales are powers of two (checked on the device, p.pow2_flag): their exponents go to the MFMA as E8M0
@@ -71,7 +76,7 @@ __global__ void __launch_bounds__(256) scales_pow2_check_kernel(const uint32_t* 
 template <bool MA_E5M2, bool MB_E5M2, bool HWS>
 __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(const GemmParams p) {
   {
-    const bool pow2 = p.pow2_flag != nullptr && *p.pow2_flag == 0;
+    const bool pow2 = fi_scales_are_pow2(p.pow2_flag);
     if (pow2 != HWS) return;
   }
   // ONE array: the compiler tells a DMA target from an LDS read by constant offsets inside one object
@@ -494,7 +499,7 @@ __global__ void __launch_bounds__(kBigThreads, 1) group_gemm_fp8_big_kernel(cons
 // flag words for the power-of-two check: a ring of slots per device (a call's three kernels read / write ITS slot;
 // calls in flight on other streams use other slots), allocated at the first call outside a stream capture
 static uint32_t* pow2_flag_slot(hipStream_t stream) {
-  constexpr int kSlots = 1024;
+  constexpr int kSlots = 1024;  // x kPow2Words words
   static uint32_t* ring[64] = {nullptr};
   static std::atomic<unsigned> next{0};
   int dev = 0;
@@ -506,11 +511,11 @@ static uint32_t* pow2_flag_slot(hipStream_t stream) {
     std::lock_guard<std::mutex> lock(mu);
     if (ring[dev] == nullptr) {
       uint32_t* ptr = nullptr;
-      if (hipMalloc(&ptr, kSlots * sizeof(uint32_t)) != hipSuccess) return nullptr;
+      if (hipMalloc(&ptr, (size_t)kSlots * kPow2Words * sizeof(uint32_t)) != hipSuccess) return nullptr;
       ring[dev] = ptr;
     }
   }
-  return ring[dev] + (next.fetch_add(1) % kSlots);
+  return ring[dev] + (size_t)(next.fetch_add(1) % kSlots) * kPow2Words;
 }
 
 template <bool HWS>
@@ -523,7 +528,7 @@ static void launch_big_variant(const GemmParams& p, int sel, int grid, hipStream
   }
 }
 
-hipError_t launch_gemm_big(const GemmParams& p_in, int grid, hipStream_t stream) {
+hipError_t launch_gemm_big(const GemmParams& p_in, int grid, hipStream_t stream, uint32_t** hws_only_flag) {
   // MFMA A operand = GEMM matrix B, MFMA B operand = GEMM matrix A
   GemmParams p = p_in;
   const int sel = (p.b_is_e5m2 ? 2 : 0) | (p.a_is_e5m2 ? 1 : 0);
@@ -539,13 +544,12 @@ hipError_t launch_gemm_big(const GemmParams& p_in, int grid, hipStream_t stream)
     const int64_t m_cnt = p.a_gran_m == 1 ? p.m_total : (p.m_total + p.a_gran_m - 1) / p.a_gran_m;
     const int64_t na = m_cnt * kblocks;
     const int64_t nb = (int64_t)(p.m_indptr ? p.num_groups : 1) * kblocks * ((p.n + 127) / 128);
-    hipError_t e = hipMemsetAsync(flag, 0, sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    scales_pow2_check_kernel<<<dim3(256), dim3(256), 0, stream>>>((const uint32_t*)p.a_scale, na, (const uint32_t*)p.b_scale,
+    scales_pow2_check_kernel<<<dim3(kPow2Words), dim3(256), 0, stream>>>((const uint32_t*)p.a_scale, na, (const uint32_t*)p.b_scale,
                                                                   nb, flag);
     launch_big_variant<true>(p, sel, grid, stream);
   }
-  launch_big_variant<false>(p, sel, grid, stream);
+  if (hws_only_flag != nullptr) *hws_only_flag = flag;
+  else launch_big_variant<false>(p, sel, grid, stream);
   return hipGetLastError();
 }
 

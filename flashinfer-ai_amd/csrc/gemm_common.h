@@ -69,6 +69,18 @@ __device__ __forceinline__ bool find_group_tile(const int32_t* m_indptr, int num
 using i32x8g = __attribute__((ext_vector_type(8))) int;
 
 // 256 x 256 tile persistent kernel (gemm_big.hip); p.num_m_tiles_bound counts 256-row tiles
-hipError_t launch_gemm_big(const GemmParams& p, int grid, hipStream_t stream);
+// The power-of-two verdict of a call: kPow2Words words, one per workgroup of the check kernel (non-zero = that
+// workgroup saw a scale that is not a positive normal power of two).  No word is ever reset: every call's check
+// kernel rewrites all of its slot's words, so there is no memset node in front of it.
+constexpr int kPow2Words = 64;
+__device__ __forceinline__ bool fi_scales_are_pow2(const uint32_t* flag) {
+  return flag != nullptr && !__any(flag[threadIdx.x & (kPow2Words - 1)] != 0);
+}
+
+// hws_only_flag == nullptr: both variants (power-of-two scales on the hardware path, anything else folded).
+// Otherwise only the hardware-scale variant, and *hws_only_flag receives the call's device flag words (fi_scales_are_pow2 after the check
+// kernel = that variant does the call; the caller's own kernel must return at once then), or nullptr when nothing
+// was launched.
+hipError_t launch_gemm_big(const GemmParams& p, int grid, hipStream_t stream, uint32_t** hws_only_flag);
 
 }  // namespace fi

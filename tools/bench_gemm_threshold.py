@@ -11,7 +11,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_gemm
     for g, m, n, k in SHAPES:
-        bench_gemm.run(g=g, m=m, n=n, k=k, tag=f"min_tiles={os.environ.get('FI_GEMM_BIG_MIN_TILES', 'default')}")
+        bench_gemm.run(g=g, m=m, n=n, k=k, tag=f"min_tiles={os.environ.get('FI_GEMM_BIG_MIN_TILES', 'default')}",
+                       quantised=os.environ.get("FI_GEMM_RAND_SCALES") != "1")
 else:
     small = len(sys.argv) > 1 and sys.argv[1] == "small"
     for thr in ("100000", "0"):
