@@ -154,6 +154,18 @@ def test_gemm_errors():
                                     # groups in between
                                     ([(37 * i) % 301 if i % 5 else 0 for i in range(150)], 264, 128)])
 def test_group_gemm_exact_many_tiles_banded_order(ms, n, k):
+    _exact_many_tiles(ms, n, k, odd_scale=False)
+
+
+@pytest.mark.parametrize("ms,n,k", [([8000], 2056, 384), ([255, 257, 6000, 1], 3584, 128)])
+def test_group_gemm_mid_size_with_one_scale_that_is_no_power_of_two(ms, n, k):
+    """Between one and four 256 x 256 tiles per CU the launcher runs the scale check and the hardware-scale 256 x 256
+    variant in front of the kernel it would have chosen anyway; ONE scale of 1.5 must send the whole call to the latter
+    (the shapes above with all-power-of-two scales take the former).  Still exact: 1.5 x small integers."""
+    _exact_many_tiles(ms, n, k, odd_scale=True)
+
+
+def _exact_many_tiles(ms, n, k, odd_scale):
     """More m tiles than one band and a ragged last band / last n tile: every (group, m tile, n tile) must
     be visited exactly once by the banded tile order of either kernel.  Small integers -> the result is exact."""
     import flashinfer
@@ -165,6 +177,8 @@ def test_group_gemm_exact_many_tiles_banded_order(ms, n, k):
     b = torch.randint(-3, 4, (g, n, k)).float()
     sa = torch.pow(2.0, torch.randint(-1, 2, (k // 128, cum)).float())
     sb = torch.pow(2.0, torch.randint(-1, 2, (g, k // 128, -(-n // 128))).float())
+    if odd_scale:
+        sa[0, cum // 2] = 1.5
     m_indptr = torch.tensor([0] + list(torch.tensor(ms).cumsum(0)), dtype=torch.int32)
     out = flashinfer.group_gemm_fp8_nt_groupwise(a.to(torch.float8_e4m3fn).to(DEV), b.to(torch.float8_e4m3fn).to(DEV),
                                                  sa.to(DEV), sb.to(DEV), m_indptr.to(DEV), out_dtype=torch.float16)
