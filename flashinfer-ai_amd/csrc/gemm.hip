@@ -631,15 +631,6 @@ static hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   const bool few_rows = p.m_indptr != nullptr && p.m_total <= 160 * (int64_t)p.num_groups;
   const bool tall = forced_tm == 128 || (forced_tm != 256 && few_rows);
   const int tall_tiles = p.num_m_tiles_bound * ceil_div(p.n, 2 * kBN);
-  if (use_dma && use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && tall && tall_tiles >= ws_min_tiles) {
-    switch (sel) {  // num_m_tiles_bound already counts 128-row tiles
-      case 0: group_gemm_fp8_dma_kernel<false, false, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
-      case 1: group_gemm_fp8_dma_kernel<false, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
-      case 2: group_gemm_fp8_dma_kernel<true, false, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
-      default: group_gemm_fp8_dma_kernel<true, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
-    }
-    return hipGetLastError();
-  }
   // 256 x 256 tiles (gemm_big.hip); FI_GEMM_BIG=0 keeps 256 x 128 / 128 x 128.  r3 (tools/bench_gemm_threshold.py):
   //  * power-of-two scales (the reference quantiser's; decided on the device): the hardware-scale variant beats the
   //    256 x 128 LDS-DMA kernel on every shape that reaches either (8 x 1024 x 4096 x 7168: 2.32 against 1.37 PFLOP/s;
@@ -663,7 +654,11 @@ static hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     return h ? atoi(h) : 4 * fi_num_compute_units();
   }();
   const int big_tiles = p.num_m_tiles_bound_ws * ceil_div(p.n, 2 * kBN);
-  const bool big_ok = use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && use_dma && big_hws_min_tiles >= 0 && !tall;
+  // groups of few rows: from ~96 rows per group on the 256 x 256 kernel with its half-empty row tiles is ahead of the
+  // 128 x 256 kernel (256 groups x 128 x 4096 x 7168: 1.03 against 0.81 PFLOP/s with power-of-two scales, 0.92 against
+  // 0.82 folded; 160 rows: 1.23 against 0.76; 64 rows: equal; 96 rows 0.69 against 0.54 / 0.53 against 0.55)
+  const bool rows_ok = forced_tm == 256 || (forced_tm == 0 && (!few_rows || p.m_total > 96 * (int64_t)p.num_groups));
+  const bool big_ok = use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && use_dma && big_hws_min_tiles >= 0 && rows_ok;
   if (big_ok && big_tiles >= big_hws_min_tiles) {
     GemmParams q = p;
     q.num_m_tiles_bound = p.num_m_tiles_bound_ws;
@@ -672,6 +667,15 @@ static hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     hipError_t e = launch_gemm_big(q, ws_grid, stream, &flag);
     if (e != hipSuccess) return e;
     p.pow2_flag = flag;  // null (no flag ring yet under a stream capture, FI_GEMM_HW_SCALES=0): nothing was launched
+  }
+  if (use_dma && use_mx && ws_min_tiles >= 0 && ws_grid >= 8 && tall && tall_tiles >= ws_min_tiles) {
+    switch (sel) {  // num_m_tiles_bound already counts 128-row tiles
+      case 0: group_gemm_fp8_dma_kernel<false, false, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+      case 1: group_gemm_fp8_dma_kernel<false, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+      case 2: group_gemm_fp8_dma_kernel<true, false, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+      default: group_gemm_fp8_dma_kernel<true, true, 128><<<dim3(ws_grid), dim3(kWsThreads), 0, stream>>>(p); break;
+    }
+    return hipGetLastError();
   }
   if (use_ws && use_dma) {
     GemmParams q = p;
