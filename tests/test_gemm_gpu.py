@@ -230,3 +230,43 @@ def test_group_gemm_random_shapes_exact(seed):
             part = a[lo:hi, kb * 128:(kb + 1) * 128].double() @ b[gi, :, kb * 128:(kb + 1) * 128].double().T
             ref[lo:hi] += part * sa[kb, lo:hi, None].double() * sb[gi, kb].double().repeat_interleave(128)[:n][None]
     torch.testing.assert_close(out.float().cpu(), ref.float().to(out_dtype).float(), atol=0, rtol=0)
+
+
+def test_group_gemm_graph_replay_follows_the_scale_kind():
+    """The choice between the hardware-scale 256 x 256 variant and the fold kernels is made on the DEVICE from the
+    scale values of each launch: a captured call replayed after the scale tensor was overwritten in place (powers of
+    two -> one scale of 1.5 -> powers of two) must give the exact result every time."""
+    import flashinfer
+
+    torch.manual_seed(5)
+    m, n, k = 8000, 2056, 384  # 32 x 9 tiles of 256 x 256: between one and four per CU
+    a = torch.randint(-3, 4, (m, k)).float()
+    b = torch.randint(-3, 4, (1, n, k)).float()
+    sa = torch.pow(2.0, torch.randint(-1, 2, (k // 128, m)).float())
+    sb = torch.pow(2.0, torch.randint(-1, 2, (1, k // 128, -(-n // 128))).float())
+    m_indptr = torch.tensor([0, m], dtype=torch.int32).to(DEV)
+    a8, b8 = a.to(torch.float8_e4m3fn).to(DEV), b.to(torch.float8_e4m3fn).to(DEV)
+    sa_d, sb_d = sa.to(DEV), sb.to(DEV)
+    out = torch.empty(m, n, device=DEV, dtype=torch.float16)
+
+    def reference(sa_h):
+        ref = torch.zeros(m, n, dtype=torch.float64)
+        for kb in range(k // 128):
+            part = a[:, kb * 128:(kb + 1) * 128].double() @ b[0, :, kb * 128:(kb + 1) * 128].double().T
+            ref += part * sa_h[kb, :, None].double() * sb[0, kb].double().repeat_interleave(128)[:n][None]
+        return ref.float().half().float()
+
+    flashinfer.group_gemm_fp8_nt_groupwise(a8, b8, sa_d, sb_d, m_indptr, out=out)  # warm-up: allocates the flag ring
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        flashinfer.group_gemm_fp8_nt_groupwise(a8, b8, sa_d, sb_d, m_indptr, out=out)
+    for odd in (False, True, False):
+        sa_h = sa.clone()
+        if odd:
+            sa_h[1, 4321] = 1.5
+        sa_d.copy_(sa_h)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.float().cpu(), reference(sa_h), atol=0, rtol=0)
