@@ -635,8 +635,9 @@ static hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
   //  * power-of-two scales (the reference quantiser's; decided on the device): the hardware-scale variant beats the
   //    256 x 128 LDS-DMA kernel on every shape that reaches either (8 x 1024 x 4096 x 7168: 2.32 against 1.37 PFLOP/s;
   //    256 tiles = one per CU: 1.27 against 1.10) and the 128 x 128 kernel from 128 tiles on (2048 x 4096 x 4096: 1.12
-  //    against 0.83) -> from one tile per CU on (below that the ~15 us of the check kernel and of the variant that
-  //    returns at once are a tenth of the call for the scales that do NOT qualify);
+  //    against 0.83, 3072 x 4096 x 4096: 1.65 against 1.13; 64 tiles: the 128 x 128 kernel's 256 workgroups win) -> from
+  //    half a tile per CU on (for scales that do NOT qualify the check kernel and the variant that returns at once
+  //    cost 5-7 us, ~7 % of the smallest such calls);
   //  * arbitrary scales (the fold variant): mixed below four tiles per CU (8 x 1024 x 4096 x 7168 1.57 against 1.32,
   //    4 x 1024 x 7168 x 2048 0.88 against 1.18) -> from 4 x CUs tiles on, as in r2.
   // In between only the hardware-scale variant is launched (it returns at once when the scales do not qualify) and
@@ -645,7 +646,7 @@ static hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     const char* e = getenv("FI_GEMM_BIG");
     if (e && atoi(e) == 0) return -1;
     const char* t = getenv("FI_GEMM_BIG_MIN_TILES");
-    return t ? atoi(t) : fi_num_compute_units();
+    return t ? atoi(t) : fi_num_compute_units() / 2;
   }();
   static const int big_fold_min_tiles = [] {
     const char* t = getenv("FI_GEMM_BIG_FOLD_MIN_TILES");
