@@ -127,13 +127,20 @@ static int ilog2_exact(int x) {
   return l;
 }
 
-// resident waves per CU the planner fills (2 per SIMD: the kernel is built for <= 256 VGPRs)
-static int decode_waves_per_cu() {
+// work items per CU the planner cuts the batch into (FI_DECODE_WAVES_PER_CU overrides).  r3 sweep over the reference
+// benchmark's grid (tools/bench_ref_grids.py, tools/r3/dsweep.py; bf16 32 / 4 and 32 / 8 heads, random and identity
+// page order): with a 16-bit cache 4 per CU is level with 8 at C2 (6.72 against 6.65 TB/s) and ahead on everything
+// smaller, where 8 cuts chunks of 256-512 tokens whose fixed cost shows (bs 256 x kv 1024: 6.46 against 5.32 -- no
+// split at all; bs 64 x kv 4096, 32 / 4: 5.84 against 4.98; bs 32 x kv 4096: 5.05 against 4.37); an fp8 cache moves
+// half the bytes per token and keeps 8 (C2 shape 6.08 against 5.59).  Counts that do not divide the chunking evenly
+// (3, 5, 6) lose 5-20 %.  A single request (fi_single_decode) always wants many chunks: 8.
+static int decode_waves_per_cu(int kv_dtype, bool batch) {
   if (const char* e = getenv("FI_DECODE_WAVES_PER_CU")) {
     int v = atoi(e);
     if (v > 0) return v;
   }
-  return 8;
+  const bool fp8 = kv_dtype == FI_DTYPE_FP8_E4M3 || kv_dtype == FI_DTYPE_FP8_E5M2;
+  return (batch && !fp8) ? 4 : 8;
 }
 
 // ref: PartitionPagedKVCacheBinarySearchMinNumPagePerBatch, scheduler.cuh:73-99
@@ -190,7 +197,7 @@ extern "C" FI_API int fi_batch_decode_plan(void* float_ws, size_t float_ws_bytes
   // launch is sized for twice the waves: measured 4.42 vs 3.73 TB/s at Hq/Hkv = 64/8 (r1)
   const uint32_t max_grid =
       max_grid_hint > 0 ? (uint32_t)max_grid_hint
-                        : (uint32_t)(fi_num_compute_units() * decode_waves_per_cu() * (head_tiles > 1 ? 2 : 1));
+                        : (uint32_t)(fi_num_compute_units() * decode_waves_per_cu(kv_dtype, true) * (head_tiles > 1 ? 2 : 1));
 
   // pages a request's chunks are cut from: all of them, or with a sliding window the ones from the page
   // holding the earliest key the last token can see (kv_len >= (pages - 1) * page_size + 1)
@@ -481,7 +488,7 @@ extern "C" FI_API int fi_single_decode_run(const fi_single_decode_params_t* a, v
   if (use_mfma) kp.head_tiles = ceil_div(kp.group_size, 32);
   // split-KV so that the chip is filled (ref: decode.cuh:689-733, kv_len > 256 -> chunks >= 256)
   const int gdy = a->num_kv_heads * kp.head_tiles;
-  const int max_grid = fi_num_compute_units() * decode_waves_per_cu();
+  const int max_grid = fi_num_compute_units() * decode_waves_per_cu(a->kv_dtype, false);
   int chunk = a->kv_len, nchunks = 1;
   if (a->kv_len > 256 && tmp) {
     const int want = std::max(1, max_grid / gdy);
