@@ -141,6 +141,23 @@ extern "C" FI_API int fi_batch_prefill_plan_tile(
       }
       kv_chunk = std::max<int64_t>(low, 128 / chunk_unit) * chunk_unit;
     }
+    // Load balance (not in the reference, whose rule above only ever splits a batch of fewer than max_items items): a
+    // mixed batch -- many short requests and a few long ones with few query rows -- otherwise ends in a tail of
+    // single workgroups walking the long requests (reference benchmark bench_batch_attention.py, 122 x (600, 1) + 8 x
+    // (10000, 17): 0.23 ms for 0.3 GB).  With W = sum of q tiles x kv length, the ideal makespan is W / max_items;
+    // chunks of at most half of that (and >= 256 tokens) let the longest-first work list even out.  A batch whose long
+    // requests also have many query rows has a large W and keeps its single chunk; graph plans keep the reference
+    // rule (their item count must stay under the captured bound).
+    // Only where the reference rule left every request whole AND the batch is uneven (longest request >= twice the
+    // mean item): an even batch gains nothing from more items (decode-only 128 x 8192 through this wrapper: -6 %), and
+    // a batch the reference rule already cut is compute-bound prefill (4 x (4096, 128): -12 % when cut finer).
+    if (fixed_split_size <= 0 && !enable_cuda_graph && kv_chunk >= max_kv_len && total_q_tiles > 0) {
+      int64_t work = 0;
+      for (int b = 0; b < batch_size; ++b) work += q_tiles[b] * kv_len[b];
+      const int64_t bal = ceil_div<int64_t>(std::max<int64_t>(work / (2 * max_items), 256), chunk_unit) * chunk_unit;
+      if (max_kv_len * total_q_tiles >= 2 * work && 2 * bal <= max_kv_len && items_at(bal) <= 8 * max_items)
+        kv_chunk = bal;
+    }
     // the partial states must fit the caller's float workspace: grow the chunks until they do (a plan
     // that cannot split at all is still correct, only less parallel)
     if (fixed_split_size <= 0) {
@@ -163,12 +180,18 @@ extern "C" FI_API int fi_batch_prefill_plan_tile(
   }
   FI_REQUIRE(kv_chunk < (1ll << 31), "batch_prefill_plan: kv chunk too large");
 
-  // work list, longest first (requests by kv_len descending; for causal masks the later = heavier q
+  // work list, costliest first (requests by rows per q tile x kv_len descending; for causal masks the later = heavier q
   // tiles first) so the tail of the launch is made of the cheapest items (ref LPT idea: scheduler.cuh:900-946)
   std::vector<int> order(batch_size);
   std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(),
-                   [&](int a, int b) { return kv_len_arr_h[a] > kv_len_arr_h[b]; });
+  // (cost of a request's items ~ rows of a q tile x kv length: in a mixed batch the compute-bound full tiles of a
+  // prefill request go out before the memory-bound one-row items of equally long decode requests and run beside
+  // them, instead of forming the tail -- bench_batch_attention.py's 254 x (8192, 1) + (8192, 4096))
+  auto item_cost = [&](int b) {
+    const int64_t rows = std::min<int64_t>((int64_t)(qo_indptr_h[b + 1] - qo_indptr_h[b]) * group, tile_q);
+    return (int64_t)kv_len_arr_h[b] * std::max<int64_t>(rows, 1);
+  };
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return item_cost(a) > item_cost(b); });
   std::vector<int32_t> req, tile, kvt;
   for (int b : order) {
     const int64_t ntiles = q_tiles[b];
@@ -179,6 +202,33 @@ extern "C" FI_API int fi_batch_prefill_plan_tile(
         tile.push_back((int32_t)(causal ? ntiles - 1 - t : t));
         kvt.push_back((int32_t)c);
       }
+  }
+  // Mixed batches: a q tile with many rows is compute-bound, one with a few rows (decode-like) streams its keys at
+  // HBM rate.  Listed one kind after the other they run as two phases; interleaved in proportion (each kind keeps its
+  // costliest-first order) the two kinds share the CUs and overlap.  Pure batches (one kind only) are unchanged.
+  {
+    std::vector<size_t> wide, narrow;
+    for (size_t i = 0; i < req.size(); ++i) {
+      const int b = req[i];
+      const int64_t rows_left = (int64_t)(qo_indptr_h[b + 1] - qo_indptr_h[b]) * group - (int64_t)tile[i] * tile_q;
+      (std::min<int64_t>(rows_left, tile_q) * 2 >= tile_q ? wide : narrow).push_back(i);
+    }
+    if (!wide.empty() && !narrow.empty()) {
+      std::vector<int32_t> r2, t2, k2;
+      const size_t n = req.size();
+      size_t iw = 0, in = 0;
+      for (size_t k = 0; k < n; ++k) {
+        // wide items are due when their share of the first k + 1 slots falls behind
+        const bool take_wide = in >= narrow.size() || (iw < wide.size() && iw * n <= k * wide.size());
+        const size_t src = take_wide ? wide[iw++] : narrow[in++];
+        r2.push_back(req[src]);
+        t2.push_back(tile[src]);
+        k2.push_back(kvt[src]);
+      }
+      req.swap(r2);
+      tile.swap(t2);
+      kvt.swap(k2);
+    }
   }
   size_t padded = req.size();
   if (enable_cuda_graph) padded = std::max<size_t>(padded, (size_t)std::max(max_items, graph_bound));

@@ -295,6 +295,14 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
   const int row0 = q_tile * kTileQ + wave * 32;  // first packed row of this wave
   const int pr = row0 + lq;
   const bool row_valid = pr < packed_len;
+  // A wave none of whose 32 rows exist (a decode-like request fills 1-8 of the tile's 128 rows) only helps staging
+  // the K / V tiles: no MFMA, no softmax.  In a mixed batch its SIMD's matrix pipe is then free for the co-resident
+  // workgroup's full tiles (wave-uniform, constant for the kernel's lifetime).
+#ifndef FI_PF_WAVE_SKIP
+#define FI_PF_WAVE_SKIP 1
+#endif
+  // (not at head_dim 256: the second path made that 512-register instantiation spill inside its loop)
+  const bool wave_active = !FI_PF_WAVE_SKIP || D == 256 || row0 < packed_len;
   const int prc = row_valid ? pr : (packed_len > 0 ? packed_len - 1 : 0);
   const int qo_idx = (int)fast_div((uint32_t)prc, p.group_div);
   const int hg = prc - qo_idx * G;
@@ -642,6 +650,22 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
     // into the idle buffer): no branch around a load, so the compiler's vmcnt counts stay exact.
     auto tile_body = [&](auto buf_c, const int t) {
       constexpr int buf = decltype(buf_c)::value;
+      if (!wave_active) {
+        // staging only (same loads, LDS writes, table duty and barrier as below; a separate straight-line path, so
+        // that the full body keeps the schedule it has without this test)
+        const int t_nx = tile_base + min(t + 1, num_tiles - 1);
+        write_k(t_nx, buf ^ 1, kst);
+        read_offsets((t + 2) & 3, roff);
+        issue_loads(k_thr, roff, kst);
+        int pg = 0, en = 0;
+        if (wave == (t & 3)) tab_lookup(tile_base + min(t + 3, num_tiles - 1), pg, en);
+        read_offsets((t + 1) & 3, roff);
+        issue_loads(v_thr, roff, vst);
+        write_v(buf ^ 1, vst);
+        if (wave == (t & 3)) tab_store((t + 3) & 3, pg, en);
+        __syncthreads();
+        return;
+      }
       asm volatile("" : "+v"(k_rd_base), "+v"(v_rd_base));
       const int t_next = tile_base + min(t + 1, num_tiles - 1);
       write_k(t_next, buf ^ 1, kst);     // K rows of tile t+1 (loaded during tile t-1)

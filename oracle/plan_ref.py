@@ -95,8 +95,8 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
       PrefillSplitQOKVIndptr           scheduler.cuh:495-614   (packed_qo_len = qo_len * G, merge_indptr)
       max_batch_size_if_split = max_grid / num_kv_heads        scheduler.cuh:716-718
     with the build's constants: a fixed 128-row q tile, chunk sizes in units of one 64-row kv tile (>= 128
-    tokens), max_grid = 2 workgroups x CUs, requests ordered by kv length descending and -- under a causal
-    mask -- the later (heavier) q tiles first."""
+    tokens), max_grid = 2 workgroups x CUs, requests ordered by (rows per q tile x kv length) descending and -- under a causal
+    mask -- the later (heavier) q tiles first; plus the build's load-balance rule for mixed batches (below)."""
     batch = len(kv_lens)
     group = num_qo_heads // num_kv_heads
     q_tiles = [ceil_div((qo_indptr[b + 1] - qo_indptr[b]) * group, tile_q) for b in range(batch)]
@@ -122,6 +122,15 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
                 else:
                     high = mid
             chunk = max(low, 128 // tile_kv) * tile_kv
+        if fixed_split_size <= 0 and not enable_cuda_graph and chunk >= max_kv and sum(q_tiles) > 0:
+            # load balance of mixed batches (the build's own rule, see prefill.hip): where the reference rule left
+            # every request whole and the longest one is >= twice the mean item, chunks of at most half the ideal
+            # makespan W / max_items, at least 256 tokens, at most 8 x max_items items
+            work = sum(q_tiles[b] * kv[b] for b in range(batch))
+            bal = ceil_div(max(work // (2 * max_items), 256), tile_kv) * tile_kv
+            if max_kv * sum(q_tiles) >= 2 * work and 2 * bal <= max_kv and \
+                    sum(q_tiles[b] * ceil_div(kv[b], bal) for b in range(batch)) <= 8 * max_items:
+                chunk = bal
         if fixed_split_size <= 0 and float_ws_bytes is not None:
             # partial states (f32 o + lse per entry and head) must fit the caller's float workspace
             def need(c):
@@ -130,7 +139,9 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
             while chunk < max_kv and need(chunk) > float_ws_bytes:
                 chunk *= 2
         split = chunk < max_kv or enable_cuda_graph
-    order = sorted(range(batch), key=lambda b: -kv_lens[b])  # stable
+    def item_cost(b):  # rows of a q tile x kv length
+        return kv_lens[b] * max(min((qo_indptr[b + 1] - qo_indptr[b]) * group, tile_q), 1)
+    order = sorted(range(batch), key=lambda b: -item_cost(b))  # stable
     req, qt, kt = [], [], []
     for b in order:
         nchunks = ceil_div(kv[b], chunk) if split else 1
@@ -139,6 +150,20 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
                 req.append(b)
                 qt.append(q_tiles[b] - 1 - t if causal else t)
                 kt.append(c)
+    # mixed batches: wide (>= half a q tile of rows, compute-bound) and narrow (decode-like, memory-bound) items are
+    # interleaved in proportion, each kind in its costliest-first order (see prefill.hip)
+    wide, narrow = [], []
+    for i in range(len(req)):
+        rows_left = (qo_indptr[req[i] + 1] - qo_indptr[req[i]]) * group - qt[i] * tile_q
+        (wide if min(rows_left, tile_q) * 2 >= tile_q else narrow).append(i)
+    if wide and narrow:
+        n, iw, i_n, idx = len(req), 0, 0, []
+        for k in range(n):
+            if i_n >= len(narrow) or (iw < len(wide) and iw * n <= k * len(wide)):
+                idx.append(wide[iw]); iw += 1
+            else:
+                idx.append(narrow[i_n]); i_n += 1
+        req, qt, kt = [req[i] for i in idx], [qt[i] for i in idx], [kt[i] for i in idx]
     merge_indptr = [0]
     if split:
         for b in range(batch):

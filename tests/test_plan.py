@@ -141,6 +141,11 @@ PREFILL_CASES = [
     ([0, 16, 32, 48, 64], [16384] * 4, 32, 8),
     ([0, 0, 7], [0, 1], 4, 4),                                        # empty request / single key
     ([0, 300], [300], 28, 4),
+    # mixed batches of the reference's bench_batch_attention.py: more q tiles than resident workgroups, so the
+    # reference rule never splits -- the build's load-balance rule cuts the few long requests
+    (list(range(123)) + [122 + 17 * (i + 1) for i in range(8)], [600] * 122 + [10000] * 8, 28, 4),
+    (list(range(129)), [8192] * 128, 28, 4),                          # decode-only through the prefill wrapper
+    (list(range(21)) + [20 + 1000], [4096] * 20 + [4096], 28, 4),     # chunked prefill: 20 decode rows + one long prompt
 ]
 
 
@@ -205,3 +210,17 @@ def test_decode_planner_sliding_window_partitions_only_the_window_pages(fi_lib):
         assert got[key] == exp[key], key
     assert got["info"][14] == 1000 and full["info"][14] == -1
     assert got["kv_chunk_size"] < full["kv_chunk_size"]  # 64 window pages, not 4096, are spread over the grid
+
+
+def test_prefill_planner_balances_a_mixed_batch(fi_lib, monkeypatch):
+    """122 one-row requests of 600 keys + 8 requests of 10 000 keys and 17 rows (bench_batch_attention.py's hybrid):
+    130 q tiles > 128 resident items, so the reference's binary search leaves every request whole and the launch ends
+    in eight lone workgroups walking 10 000 keys.  The balance rule cuts chunks of about W / (2 x 128) tokens."""
+    monkeypatch.setenv("FI_NUM_CUS", "256")
+    qo_indptr = list(range(123)) + [122 + 17 * (i + 1) for i in range(8)]
+    kv_lens = [600] * 122 + [10000] * 8
+    got = run_prefill_plan(fi_lib, qo_indptr, kv_lens, 28, 4, causal=True)
+    assert got["split_kv"] and got["kv_chunk_size"] == 640          # (122 x 600 + 8 x 10 000) / 256 = 598 -> 640
+    assert got["num_work"] == 122 + 8 * 16
+    graph = run_prefill_plan(fi_lib, qo_indptr, kv_lens, 28, 4, causal=True, cuda_graph=True)
+    assert graph["kv_chunk_size"] >= 10000 and graph["num_work"] == 130   # graph plans keep the reference rule

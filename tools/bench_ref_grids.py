@@ -5,7 +5,8 @@
   prefill  benchmarks/bench_hopper_fp8_attention.py:20-75  single_prefill_with_kv_cache_return_lse, f16 and fp8 e4m3 q / k /
            v, seq 4096 / 8192 / 16384, 24 / 32 heads (MHA), causal and not, head_dim 64 / 128 / 256; TFLOP/s by the file's
            formula (causal counted as half)
-Usage: python tools/bench_ref_grids.py decode|prefill"""
+  mixed    benchmarks/bench_batch_attention.py (see mixed_grid)
+Usage: python tools/bench_ref_grids.py decode|prefill|mixed"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flashinfer-ai_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -53,5 +54,48 @@ def prefill_grid():
                     print(f"{seq:7d} {heads:5d} {int(causal):6d} {d:8d} {fl / m16 / 1e9:12.1f} {fl / m8 / 1e9:14.1f}", flush=True)
 
 
+
+
+def mixed_grid():
+    """benchmarks/bench_batch_attention.py:96-152: BatchPrefillWithPagedKVCacheWrapper on six (kv_len, qo_len) mixes
+    (decode-only, prefill-only, two hybrids, two random), page 1 / 8 / 16, head_dim 64 / 128, 28 / 4 heads, bf16, causal;
+    GB/s = (q + cache bytes) / time with the file's 1024-based units, plus TFLOP/s by the reference's causal formula."""
+    import numpy as np
+    np.random.seed(42)
+    torch.random.manual_seed(42)
+    cfgs = [[(8192, 1)] * 128, [(4096, 128)] * 4, [(600, 1)] * 122 + [(10_000, 17)] * 8, [(8192, 1)] * 127 * 2 + [(8192, 4096)] * 1]
+
+    def rand_case(bsz, lo, hi):
+        full = np.random.randint(lo, hi, size=bsz)
+        return [(int(kv), 17) if i % 16 == 0 else (int(kv * 0.05), 1) for i, kv in enumerate(full)]
+    cfgs.append(rand_case(256, 1000, 8192))
+    cfgs.append(rand_case(128, 2000, 16_000))
+    names = ["decode-only 128 x kv 8192", "prefill-only 4 x (4096, 128)", "hybrid 122 x (600, 1) + 8 x (10000, 17)",
+             "chunked prefill 254 x (8192, 1) + (8192, 4096)", "random 256", "random 128"]
+    hq, hkv = 28, 4
+    ws = torch.empty(128 << 20, dtype=torch.uint8, device=DEV)
+    print("config                                            page head_dim     ms    GiB/s   TFLOP/s", flush=True)
+    for name, pairs in zip(names, cfgs):
+        for page in (1, 8, 16):
+            for d in (64, 128):
+                kv_lens = torch.tensor([p[0] for p in pairs], dtype=torch.int32)
+                q_lens = torch.tensor([p[1] for p in pairs], dtype=torch.int32)
+                blocks_per = torch.ceil(kv_lens / page).int()
+                q_indptr = torch.cat([torch.tensor([0]), torch.cumsum(q_lens, 0)]).int()
+                kv_indptr = torch.cat([torch.tensor([0]), torch.cumsum(blocks_per, 0)]).int()
+                nb = int(kv_indptr[-1])
+                q = torch.rand(int(q_indptr[-1]), hq, d, dtype=torch.bfloat16, device=DEV)
+                kv = torch.randn(nb, 2, page, hkv, d, dtype=torch.bfloat16, device=DEV)
+                w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(ws, kv_layout="NHD", backend="fa2")
+                w.plan(q_indptr.to(DEV), kv_indptr.to(DEV), torch.arange(nb, dtype=torch.int32, device=DEV),
+                       ((kv_lens - 1) % page + 1).to(DEV), hq, hkv, d, page, causal=True,
+                       q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16)
+                med, _ = bench(lambda: w.run(q, kv), iters=9, warm=2)
+                byt = q.numel() * 2 + kv.numel() * 2
+                fl = sum((2 * kv_ - q_) * q_ * hq * 2 * d for kv_, q_ in pairs)
+                print(f"{name:48s} {page:5d} {d:8d} {med:8.4f} {byt / med / 1e-3 / 1024 ** 3:8.1f} {fl / med / 1e9:8.1f}", flush=True)
+                del kv, w
+
+
 if __name__ == "__main__":
-    (decode_grid if sys.argv[1] == "decode" else prefill_grid)()
+    {"decode": decode_grid, "prefill": prefill_grid, "mixed": mixed_grid}[sys.argv[1]]()

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 python -m pytest tests/test_prefill_gpu.py tests/test_fuzz_gpu.py tests/test_page_cascade_gpu.py -x -q -m gpu 2>&1 | tail -3 || exit 1
+timeout -k 10 600 python tools/bench_ref_grids.py mixed > gpurun_out/r03_mixed_ref_grid_skip.txt 2>&1
+grep -v amdgpu gpurun_out/r03_mixed_ref_grid_skip.txt | awk '$0 ~ /128 +[0-9.]+ +[0-9.]+ +[0-9.]+$/' 
+timeout -k 10 300 python tools/bench_prefill.py 2>&1 | grep -v amdgpu | tail -12
