@@ -140,6 +140,38 @@ extern "C" FI_API int fi_batch_prefill_plan_tile(
         if (items_at(mid * chunk_unit) > max_items) low = mid + 1; else high = mid;
       }
       kv_chunk = std::max<int64_t>(low, 128 / chunk_unit) * chunk_unit;
+      // The reference rule cuts as fine as max_items allows.  On this part that over-splits whenever the batch has
+      // rows to merge: every chunk writes, and the merge reads back, an f32 partial row per query row and head (bs 1,
+      // qo = kv = 1024: 82 us split in two against 31 us whole; bs 2, 512 x 4096: 132 against 95), while few-row
+      // requests gain a lot (bs 1, 16 x 8192: 28 against 159 us).  So the candidates chunk, 2 x chunk, 4 x chunk ...
+      // and "whole" are priced with a two-term model -- workgroup rounds per CU x tokens per item x 20 ns (per 256 of
+      // head_dim_qk + head_dim_vo), plus for a split 6 us + partial-state bytes at 3 TB/s -- and the cheapest wins
+      // (ties: the coarser).  Graph plans keep the reference rule (they always split).
+      if (!enable_cuda_graph) {
+        const int64_t cus = fi_num_compute_units();
+        const int64_t tok_ns = std::max<int64_t>(20 * (head_dim_qk + head_dim_vo) / 256, 1);
+        auto cost_ns = [&](int64_t chunk, bool split) {
+          int64_t items = 0, entries = 0;
+          for (int b = 0; b < batch_size; ++b) {
+            const int64_t nc = split ? ceil_div<int64_t>(kv_len[b], chunk) : 1;
+            items += q_tiles[b] * nc;
+            entries += (int64_t)(qo_indptr_h[b + 1] - qo_indptr_h[b]) * nc;
+          }
+          int64_t t = ceil_div<int64_t>(items * num_kv_heads, cus) * std::min(chunk, max_kv_len) * tok_ns;
+          if (split) t += 6000 + entries * num_qo_heads * head_dim_vo * 8 / 3000;
+          return t;
+        };
+        const int64_t whole = ceil_div<int64_t>(max_kv_len, chunk_unit) * chunk_unit;
+        int64_t best = whole, best_cost = cost_ns(whole, false);
+        for (int64_t c = kv_chunk; c < max_kv_len; c *= 2) {
+          const int64_t t = cost_ns(c, true);
+          if (t < best_cost || (t == best_cost && c > best && best != whole)) {
+            best = c;
+            best_cost = t;
+          }
+        }
+        kv_chunk = best;
+      }
     }
     // Load balance (not in the reference, whose rule above only ever splits a batch of fewer than max_items items): a
     // mixed batch -- many short requests and a few long ones with few query rows -- otherwise ends in a tail of

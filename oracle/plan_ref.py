@@ -122,6 +122,28 @@ def prefill_plan_ref(qo_indptr: List[int], kv_lens: List[int], num_qo_heads: int
                 else:
                     high = mid
             chunk = max(low, 128 // tile_kv) * tile_kv
+            if not enable_cuda_graph:
+                # the build's price model (prefill.hip): chunk, 2 x chunk, ... and "whole"; rounds per CU x tokens per
+                # item x 20 ns (per 256 of head_dim_qk + head_dim_vo) + for a split 6 us + partial bytes at 3 TB/s
+                tok_ns = max(20 * (2 * head_dim) // 256, 1)
+
+                def cost_ns(c, split_):
+                    items = sum(q_tiles[b] * (ceil_div(kv[b], c) if split_ else 1) for b in range(batch))
+                    entries = sum((qo_indptr[b + 1] - qo_indptr[b]) * (ceil_div(kv[b], c) if split_ else 1)
+                                  for b in range(batch))
+                    t = ceil_div(items * num_kv_heads, num_cus) * min(c, max_kv) * tok_ns
+                    if split_:
+                        t += 6000 + entries * num_qo_heads * head_dim * 8 // 3000
+                    return t
+                whole = ceil_div(max_kv, tile_kv) * tile_kv
+                best, best_cost = whole, cost_ns(whole, False)
+                c = chunk
+                while c < max_kv:
+                    t = cost_ns(c, True)
+                    if t < best_cost or (t == best_cost and c > best and best != whole):
+                        best, best_cost = c, t
+                    c *= 2
+                chunk = best
         if fixed_split_size <= 0 and not enable_cuda_graph and chunk >= max_kv and sum(q_tiles) > 0:
             # load balance of mixed batches (the build's own rule, see prefill.hip): where the reference rule left
             # every request whole and the longest one is >= twice the mean item, chunks of at most half the ideal

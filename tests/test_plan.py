@@ -175,9 +175,9 @@ def test_prefill_planner_grows_chunks_to_fit_the_float_workspace(fi_lib, monkeyp
     from oracle.plan_ref import prefill_plan_ref
 
     monkeypatch.setenv("FI_NUM_CUS", "256")
-    qo_indptr, kv_lens, hq, hkv = [0, 512], [65536], 32, 8
+    qo_indptr, kv_lens, hq, hkv = [0, 64], [65536], 32, 8
     roomy = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv)
-    tight_bytes = 24 << 20
+    tight_bytes = roomy["merge_indptr"][-1] * hq * 129 * 4 * 3 // 4   # three quarters of what the roomy plan's states take
     tight = run_prefill_plan(fi_lib, qo_indptr, kv_lens, hq, hkv, float_bytes=tight_bytes)
     exp = prefill_plan_ref(qo_indptr, kv_lens, hq, hkv, float_ws_bytes=tight_bytes)
     assert roomy["split_kv"] and tight["split_kv"] and tight["kv_chunk_size"] > roomy["kv_chunk_size"]
