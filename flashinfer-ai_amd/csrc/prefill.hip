@@ -74,6 +74,37 @@ static int compute_type(int q_dt, int o_dt) {
 
 using namespace fi;
 
+// Chunk choice by price (see fi_batch_prefill_plan): the reference chunk, its doublings and "whole" (returned as the
+// kv span rounded up to a kv tile); rounds of workgroups per CU x tokens per item x 20 ns per 256 of head_dim_qk +
+// head_dim_vo, for a split + 6 us + partial-state bytes at 3 TB/s; ties go to the coarser.
+static int64_t price_kv_chunk(int64_t ref_chunk, int64_t max_kv_len, int n, const int64_t* q_tiles, const int64_t* kv_len,
+                              const int64_t* qo_rows, int num_kv_heads, int num_qo_heads, int head_dim_qk,
+                              int head_dim_vo) {
+  const int64_t cus = fi_num_compute_units();
+  const int64_t tok_ns = std::max<int64_t>(20 * (head_dim_qk + head_dim_vo) / 256, 1);
+  auto cost_ns = [&](int64_t chunk, bool split) {
+    int64_t items = 0, entries = 0;
+    for (int b = 0; b < n; ++b) {
+      const int64_t nc = split ? ceil_div<int64_t>(kv_len[b], chunk) : 1;
+      items += q_tiles[b] * nc;
+      entries += qo_rows[b] * nc;
+    }
+    int64_t t = ceil_div<int64_t>(items * num_kv_heads, cus) * std::min(chunk, max_kv_len) * tok_ns;
+    if (split) t += 6000 + entries * num_qo_heads * head_dim_vo * 8 / 3000;
+    return t;
+  };
+  const int64_t whole = ceil_div<int64_t>(max_kv_len, kTileKV) * kTileKV;
+  int64_t best = whole, best_cost = cost_ns(whole, false);
+  for (int64_t c = ref_chunk; c < max_kv_len; c *= 2) {
+    const int64_t t = cost_ns(c, true);
+    if (t < best_cost || (t == best_cost && c > best && best != whole)) {
+      best = c;
+      best_cost = t;
+    }
+  }
+  return best;
+}
+
 extern "C" FI_API int fi_batch_prefill_plan_tile(
     void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws, size_t int_ws_bytes,
     const int32_t* qo_indptr_h, const int32_t* kv_indptr_h, const int32_t* kv_len_arr_h,
@@ -148,29 +179,10 @@ extern "C" FI_API int fi_batch_prefill_plan_tile(
       // head_dim_qk + head_dim_vo), plus for a split 6 us + partial-state bytes at 3 TB/s -- and the cheapest wins
       // (ties: the coarser).  Graph plans keep the reference rule (they always split).
       if (!enable_cuda_graph) {
-        const int64_t cus = fi_num_compute_units();
-        const int64_t tok_ns = std::max<int64_t>(20 * (head_dim_qk + head_dim_vo) / 256, 1);
-        auto cost_ns = [&](int64_t chunk, bool split) {
-          int64_t items = 0, entries = 0;
-          for (int b = 0; b < batch_size; ++b) {
-            const int64_t nc = split ? ceil_div<int64_t>(kv_len[b], chunk) : 1;
-            items += q_tiles[b] * nc;
-            entries += (int64_t)(qo_indptr_h[b + 1] - qo_indptr_h[b]) * nc;
-          }
-          int64_t t = ceil_div<int64_t>(items * num_kv_heads, cus) * std::min(chunk, max_kv_len) * tok_ns;
-          if (split) t += 6000 + entries * num_qo_heads * head_dim_vo * 8 / 3000;
-          return t;
-        };
-        const int64_t whole = ceil_div<int64_t>(max_kv_len, chunk_unit) * chunk_unit;
-        int64_t best = whole, best_cost = cost_ns(whole, false);
-        for (int64_t c = kv_chunk; c < max_kv_len; c *= 2) {
-          const int64_t t = cost_ns(c, true);
-          if (t < best_cost || (t == best_cost && c > best && best != whole)) {
-            best = c;
-            best_cost = t;
-          }
-        }
-        kv_chunk = best;
+        std::vector<int64_t> rows(batch_size);
+        for (int b = 0; b < batch_size; ++b) rows[b] = qo_indptr_h[b + 1] - qo_indptr_h[b];
+        kv_chunk = price_kv_chunk(kv_chunk, max_kv_len, batch_size, q_tiles.data(), kv_len.data(), rows.data(),
+                                  num_kv_heads, num_qo_heads, head_dim_qk, head_dim_vo);
       }
     }
     // Load balance (not in the reference, whose rule above only ever splits a batch of fewer than max_items items): a
@@ -335,6 +347,7 @@ extern "C" FI_API int fi_batch_prefill_plan_tile(
                                (hipStream_t)stream));
   return 0;
 }
+
 
 extern "C" FI_API int fi_batch_prefill_plan(
     void* float_ws, size_t float_ws_bytes, void* int_ws, void* pinned_int_ws, size_t int_ws_bytes,
@@ -577,6 +590,11 @@ extern "C" FI_API int fi_single_prefill_run(const fi_single_prefill_params_t* a,
       if (q_tiles * ceil_div<int64_t>(span, mid * kTileKV) > max_items) low = mid + 1; else high = mid;
     }
     int64_t chunk = std::max<int64_t>(low, 128 / kTileKV) * kTileKV;
+    {
+      const int64_t rows = a->qo_len;
+      chunk = price_kv_chunk(chunk, span, 1, &q_tiles, &span, &rows, a->num_kv_heads, a->num_qo_heads, a->head_dim,
+                             a->head_dim);
+    }
     auto need = [&](int64_t c) {
       return ((int64_t)a->qo_len * ceil_div<int64_t>(span, c) * a->num_qo_heads * (a->head_dim + 1) + 64) *
              (int64_t)sizeof(float);
