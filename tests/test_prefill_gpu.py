@@ -349,6 +349,27 @@ def test_batch_prefill_split_kv_matches_oracle_and_unsplit(dtype, causal, qo_len
         torch.testing.assert_close(lse2, lse, rtol=1e-3, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_batch_prefill_mixed_batch_balance_rule_and_idle_waves(dtype):
+    """A mixed batch in the shape of the reference's bench_batch_attention.py hybrids, scaled down: 132 decode-like
+    requests (one query token = 7 of a tile's 128 packed rows: three of the four waves have no row and only help
+    staging) + 4 long requests of 17 query tokens + one prompt of 300 tokens (wide tiles, interleaved with the narrow
+    ones in the work list).  137+ q tiles exceed the resident-workgroup budget, so the reference rule leaves every
+    request whole; the balance rule must cut the long ones.  Result against the oracle, and equal to the unsplit plan."""
+    hq, hkv, d, ps = 28, 4, 128, 16
+    kv_lens = [200 + 3 * i for i in range(132)] + [5000, 4321, 4097, 3500] + [700]
+    qo_lens = [1] * 132 + [17] * 4 + [300]
+    w, q, cache, qo_indptr, indptr, indices, last, o, lse = _plan_run(qo_lens, kv_lens, hq, hkv, d, ps, dtype, True, seed=77)
+    assert w._plan_info[14] == 1 and w._plan_info[9] < 4097 and w._plan_info[12] > 132 + 4 + 17  # split, extra items
+    o_ref, lse_ref = R.batch_prefill_ref(q.float(), qo_indptr, cache.float(), "NHD", indptr, indices, last, causal=True)
+    torch.testing.assert_close(o.float().cpu(), o_ref.float(), **ptol(dtype))
+    torch.testing.assert_close(lse.cpu(), lse_ref.float(), rtol=1e-3, atol=1e-3)
+    w2, *_, o2, lse2 = _plan_run(qo_lens, kv_lens, hq, hkv, d, ps, dtype, True, seed=77, disable_split_kv=True)
+    assert w2._plan_info[14] == 0
+    torch.testing.assert_close(o2.float().cpu(), o_ref.float(), **ptol(dtype))
+    torch.testing.assert_close(lse2, lse, rtol=1e-3, atol=1e-3)
+
+
 def test_batch_prefill_split_kv_fp8_native_and_rows_without_keys():
     # fp8 attention through the split path against the unsplit run
     hq, hkv, d, ps = 8, 2, 128, 16
