@@ -6,7 +6,8 @@
            v, seq 4096 / 8192 / 16384, 24 / 32 heads (MHA), causal and not, head_dim 64 / 128 / 256; TFLOP/s by the file's
            formula (causal counted as half)
   mixed    benchmarks/bench_batch_attention.py (see mixed_grid)
-Usage: python tools/bench_ref_grids.py decode|prefill|mixed"""
+  hopper   benchmarks/bench_hopper_attention.py (see hopper_grid)
+Usage: python tools/bench_ref_grids.py decode|prefill|mixed|hopper"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "flashinfer-ai_amd")); sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -97,5 +98,35 @@ def mixed_grid():
                 del kv, w
 
 
+def hopper_grid():
+    """benchmarks/bench_hopper_attention.py:196-210: f16, 32 / 32 heads, head_dim 128, causal, batch x seq_len = 131 072
+    tokens; paged prefill with separate K / V page tensors at page_size 1 and 16, and ragged prefill.  TFLOP/s by the
+    file's formula (causal counted as half)."""
+    hq = hkv = 32; d = 128
+    print("kind    page  batch  seq_len      ms   TFLOP/s", flush=True)
+    for page in (1, 16):
+        for bs, seq in ((128, 1024), (64, 2048), (32, 4096), (16, 8192), (1, 32768)):
+            q = torch.randn(bs * seq, hq, d, dtype=torch.half, device=DEV)
+            k = torch.randn(bs * seq // page, page, hkv, d, dtype=torch.half, device=DEV)
+            v = torch.randn(bs * seq // page, page, hkv, d, dtype=torch.half, device=DEV)
+            w = flashinfer.BatchPrefillWithPagedKVCacheWrapper(torch.empty(256 << 20, dtype=torch.uint8, device=DEV), kv_layout="NHD", backend="fa2")
+            qo_indptr = torch.arange(0, bs * seq + 1, seq).int()
+            kv_indptr = torch.arange(0, bs * seq // page + 1, seq // page).int()
+            w.plan(qo_indptr.to(DEV), kv_indptr.to(DEV), torch.arange(0, bs * seq // page, dtype=torch.int32, device=DEV),
+                   torch.ones(bs, dtype=torch.int32, device=DEV) * page, hq, hkv, d, page, causal=True)
+            med, _ = bench(lambda: w.run(q, (k, v)), iters=7, warm=2)
+            print(f"paged  {page:5d} {bs:6d} {seq:8d} {med:8.3f} {bs * seq * seq * hq * d * 2 / med / 1e9:9.1f}", flush=True)
+            del k, v, w
+    for bs, seq in ((128, 1024), (64, 2048), (32, 4096), (16, 8192), (1, 32768)):
+        q = torch.randn(bs * seq, hq, d, dtype=torch.half, device=DEV)
+        k = torch.randn(bs * seq, hkv, d, dtype=torch.half, device=DEV)
+        v = torch.randn(bs * seq, hkv, d, dtype=torch.half, device=DEV)
+        w = flashinfer.BatchPrefillWithRaggedKVCacheWrapper(torch.empty(256 << 20, dtype=torch.uint8, device=DEV), kv_layout="NHD", backend="fa2")
+        ind = torch.arange(0, bs * seq + 1, seq).int().to(DEV)
+        w.plan(ind, ind, hq, hkv, d, causal=True)
+        med, _ = bench(lambda: w.run(q, k, v), iters=7, warm=2)
+        print(f"ragged     - {bs:6d} {seq:8d} {med:8.3f} {bs * seq * seq * hq * d * 2 / med / 1e9:9.1f}", flush=True)
+
+
 if __name__ == "__main__":
-    {"decode": decode_grid, "prefill": prefill_grid, "mixed": mixed_grid}[sys.argv[1]]()
+    {"decode": decode_grid, "prefill": prefill_grid, "mixed": mixed_grid, "hopper": hopper_grid}[sys.argv[1]]()
