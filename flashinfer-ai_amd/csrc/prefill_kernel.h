@@ -223,6 +223,12 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
 #ifndef FI_PF_ACC_AGPR
 #define FI_PF_ACC_AGPR 1
 #endif
+#ifndef FI_PF_QK_PREFETCH_256
+#define FI_PF_QK_PREFETCH_256 4
+#endif
+#ifndef FI_PF_PV_PREFETCH
+#define FI_PF_PV_PREFETCH 3  // head_dim 256: V^T fragments in flight ahead of their P.V MFMA (0: read right before use)
+#endif
   // head_dim 256 (one wave per SIMD, 512 registers = 256 vector + 256 accumulator): O and Q in accumulator registers
   constexpr bool ACC_AGPR = FI_PF_ACC_AGPR && D == 256 && !Q_FP8;
   using MPV = MfmaType<TPV>;
@@ -689,7 +695,8 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
         for (int r = 0; r < 16; ++r) s_acc[kbk][r] = 0.f;
       {
         constexpr int NK = 2 * KSTEPS;
-        constexpr int PF = ROPE ? 1 : GENERAL ? 2 : kQkPrefetch;  // feature / RoPE variants: fewer fragments in flight (registers)
+        // feature / RoPE variants: fewer fragments in flight (registers); head_dim 256 (one wave per SIMD): deeper
+        constexpr int PF = ROPE ? 1 : GENERAL ? 2 : (D == 256 ? FI_PF_QK_PREFETCH_256 : kQkPrefetch);
         u32x4 kf[NK];
         auto rd = [&](int i) {
           return *(const u32x4*)(kb + (i / KSTEPS) * 32 * ROWB + k_rd(i % KSTEPS));
@@ -825,6 +832,8 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
       // ---- O^T += V^T P^T ----
       // P^T fragments: accumulator registers 8s..8s+7 of block kb, rounded to 16 bit, are the B operand of
       // k-step s (built right before use to keep registers free for LDS prefetch)
+      using pv_ring_t = __attribute__((ext_vector_type(8))) short;
+      [[maybe_unused]] pv_ring_t pv_ring[FI_PF_PV_PREFETCH > 0 ? FI_PF_PV_PREFETCH : 1];
 #pragma unroll
       for (int kbk = 0; kbk < 2; ++kbk) {
 #pragma unroll
@@ -861,6 +870,34 @@ __global__ void __launch_bounds__(kPrefillThreads, D == 256 ? 1 : 2)
           }
           using pv_frag_t = typename MPV::frag;
           const pv_frag_t pfrag = __builtin_bit_cast(pv_frag_t, w);
+          if constexpr (ACC_AGPR && FI_PF_PV_PREFETCH > 0) {
+            // One wave per SIMD (head_dim 256): nobody hides an LDS round trip, and with {read, read, wait, MFMA} per
+            // block the matrix pipe idled through 32 of them per tile.  The V^T fragments run FI_PF_PV_PREFETCH
+            // blocks ahead of their MFMA (across the four (kbk, s2) groups: vfrag_at flattens the index).
+            using s16x8 = __attribute__((ext_vector_type(8))) short;
+            constexpr int PFV = FI_PF_PV_PREFETCH;
+            auto vfrag_at = [&](int idx) {
+              const char* base = vb + (32 * (idx / (2 * DBLK)) + 16 * ((idx / DBLK) & 1)) * ROWB + v_rd(idx % DBLK);
+              const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+              const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 8 * ROWB));
+              return s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            };
+            const int g0 = (2 * kbk + s2) * DBLK;  // first flattened index of this group
+            if (g0 == 0) {
+#pragma unroll
+              for (int i = 0; i < PFV; ++i) pv_ring[i] = vfrag_at(i);
+            }
+#pragma unroll
+            for (int db = 0; db < DBLK; ++db) {
+              const int idx = g0 + db;
+              const s16x8 a8 = pv_ring[idx % PFV];
+              if (idx + PFV < 4 * DBLK) pv_ring[idx % PFV] = vfrag_at(idx + PFV);
+              mfma16_asm<TPV, true, false>(o_acc[db], __builtin_bit_cast(pv_frag_t, a8), pfrag);
+              if constexpr (P_HI_LO)
+                mfma16_asm<T16, true, false>(o_acc[db], __builtin_bit_cast(frag_t, a8), __builtin_bit_cast(frag_t, w_lo));
+            }
+            continue;
+          }
 #pragma unroll
           for (int db = 0; db < DBLK; ++db) {
             const char* base = vb + (32 * kbk + 16 * s2) * ROWB + v_rd(db);
