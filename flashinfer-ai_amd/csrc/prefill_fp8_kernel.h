@@ -529,20 +529,34 @@ __global__ void __launch_bounds__(NW * 64, (NW == 8 || D == 256) ? 1 : 2) batch_
         const i32x8 p8 = {p8w[0], p8w[1], p8w[2], p8w[3], p8w[4], p8w[5], p8w[6], p8w[7]};
         // V^T fragments two head_dim blocks at a time (the stage base goes into the address register: at head_dim 256
         // the V ring starts beyond the 16-bit offset field of the LDS instructions)
+        // (one workgroup per CU at head_dim 256, i.e. one wave per SIMD: the pair after next is read BEFORE this pair's
+        // MFMAs are issued, otherwise every pair stands through an LDS round trip with the matrix pipe empty)
+        i32x2 vfa[2][4], vfb[2][4];
+        auto v_pair_read = [&](int db, int slot) {
+          const int a0 = v_rd[db] + VB, a1 = v_rd[db + 1] + VB;
+          vfa[slot][0] = lds_tr8<0 * TRR>(a0);
+          vfa[slot][1] = lds_tr8<1 * TRR>(a0);
+          vfa[slot][2] = lds_tr8<2 * TRR>(a0);
+          vfa[slot][3] = lds_tr8<3 * TRR>(a0);
+          vfb[slot][0] = lds_tr8<0 * TRR>(a1);
+          vfb[slot][1] = lds_tr8<1 * TRR>(a1);
+          vfb[slot][2] = lds_tr8<2 * TRR>(a1);
+          vfb[slot][3] = lds_tr8<3 * TRR>(a1);
+        };
+        v_pair_read(0, 0);
 #pragma unroll
         for (int db = 0; db < DBLK; db += 2) {
-          const int a0 = v_rd[db] + VB, a1 = v_rd[db + 1] + VB;
-          i32x2 va[4], vb[4];
-          va[0] = lds_tr8<0 * TRR>(a0);
-          va[1] = lds_tr8<1 * TRR>(a0);
-          va[2] = lds_tr8<2 * TRR>(a0);
-          va[3] = lds_tr8<3 * TRR>(a0);
-          vb[0] = lds_tr8<0 * TRR>(a1);
-          vb[1] = lds_tr8<1 * TRR>(a1);
-          vb[2] = lds_tr8<2 * TRR>(a1);
-          vb[3] = lds_tr8<3 * TRR>(a1);
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+          const int cur = (db >> 1) & 1;
+          i32x2(&va)[4] = vfa[cur];
+          i32x2(&vb)[4] = vfb[cur];
+          if (db + 2 < DBLK) {
+            v_pair_read(db + 2, cur ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(8)"
+                         : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+          } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(va[0]), "+v"(va[1]), "+v"(va[2]), "+v"(va[3]), "+v"(vb[0]), "+v"(vb[1]), "+v"(vb[2]), "+v"(vb[3]));
+          }
           __builtin_amdgcn_sched_barrier(0);  // an MFMA is no memory operation: keep it behind the wait (guide 5.4 rule 18)
           o_acc[db] = mfma_fp8_k64_fmt<BF8>(
               i32x8{va[0][0], va[0][1], va[1][0], va[1][1], va[2][0], va[2][1], va[3][0], va[3][1]}, p8, o_acc[db]);
